@@ -1,0 +1,153 @@
+/*
+ * sy_env.h — C ABI of the MI355X-native batched Scotland-Yard environment engine.
+ *
+ * This is the drop-in boundary for the reference's env.step hot path.  The reference
+ * (elte-collective-intelligence/student-mechanism-design) has no FFI of its own: its boundary is
+ * the Python class CustomEnvironment (src/environment/yard.py).  Each entry point below names the
+ * reference interface it replaces (file:line under /root/reference/src); INTEGRATION.md shows the
+ * ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no torch / C++ types in signatures.
+ *   - every pointer documented "device" is device memory owned by the CALLER (e.g. torch tensors);
+ *     it must stay alive until the work enqueued on `stream` has finished.
+ *   - every call is asynchronous on the hipStream_t passed as `void *stream` (NULL = null stream);
+ *     nothing here synchronises, allocates device memory, or copies (graph-capture safe), except
+ *     sy_env_create / sy_env_destroy (host allocation only).
+ *   - return value: 0 = ok, <0 = error (SY_ERR_*); sy_last_error() gives a thread-local message.
+ *     Nothing throws across the ABI.  One host thread per handle.
+ *   - invalid / unaffordable / blocked / -1 actions never fail: the agent stays (yard.py:168-229).
+ *
+ * Layouts (B envs, A = P+1 agents, N nodes, NS = node stride (multiple of 16, >= N), D = 16)
+ *   pos, budget      int32  [B][A]      agent 0 = MrX, agent k+1 = Police k      (yard.py:125-126,117-119)
+ *   t                int32  [B]         env timestep                              (yard.py:127,355)
+ *   step_count       uint32 [B]         steps since the last full reset (RNG counter)
+ *   visits           uint16 [B][NS]     police node_visit_counts                  (yard.py:244-245)
+ *   belief           float  [B][NS]     police belief over MrX's node             (belief_module.py:69-111)
+ *   mask             uint8  [B][A][NS]  action mask, 1 = legal                    (yard.py:297-327)
+ *   reward           double [B][A]      (reward_calculator.py:26-266; float64 like the reference)
+ *   terminated/truncated uint8 [B], winner int8 [B] (0 none, 1 Police, 2 MrX)     (reward_calculator.py:63-90)
+ *   graph pool: ell uint32 [G][N][16]  = neighbour id | (edge weight << 16), rows sorted by neighbour
+ *               id, padding entries = N | 0xFFFF0000;  apsp uint16 [G][N][N] weighted shortest paths
+ *               (replaces pathfinding.py:34-137);  inv_deg float [G][NS] = 1/deg (0 if isolated);
+ *               env_graph int32 [B]: graph of each env — all envs of one launch block (envs
+ *               [k*waves_per_block, (k+1)*waves_per_block)) use the graph of the block's first env.
+ */
+#ifndef SY_ENV_H
+#define SY_ENV_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SY_ABI_VERSION 1
+#define SY_ELL_WIDTH 16
+#define SY_MAX_AGENTS 8
+#define SY_MAX_NODES 1024
+#define SY_NUM_WEIGHTS 11
+#define SY_MRX_MONEY 1000 /* MAX_MONEY_LIMIT yard.py:11 */
+
+#define SY_OK 0
+#define SY_ERR_INVALID (-1)  /* bad argument / config */
+#define SY_ERR_STATE (-2)    /* call order (e.g. step before bind) */
+#define SY_ERR_HIP (-3)      /* a HIP runtime call failed */
+
+typedef struct sy_env sy_env; /* opaque */
+
+typedef struct sy_env_config {
+    int32_t num_envs;          /* B, envs on THIS GPU                                         */
+    int32_t num_nodes;         /* N  (graph_nodes, yard.py:25,52)                             */
+    int32_t num_police;        /* P  (`number_of_agents`, yard.py:20,33)                      */
+    int32_t agent_money;       /* police budget at reset (yard.py:21,117-119)                 */
+    int32_t max_timestep;      /* truncation when t > max_timestep; reference: 250            */
+    int32_t num_graphs;        /* G, graphs in the pool                                       */
+    int32_t node_stride;       /* NS, multiple of 16, >= N                                    */
+    int32_t reveal_interval;   /* MrX revealed to the belief when t_post % k == 0; 0 = never  */
+    int32_t police_evidence;   /* 1: belief is zeroed on police-occupied nodes                */
+    int32_t belief_init_onehot;/* 1: belief starts as a delta on MrX's start (else uniform)   */
+    int32_t auto_reset;        /* 1: a finished episode restarts inside step/rollout          */
+    int32_t waves_per_block;   /* envs per launch block (1..16); 0 = engine default           */
+    uint64_t env_id_offset;    /* global index of env 0 (rank * B): distinct RNG sub-streams  */
+} sy_env_config;
+
+/* device buffers of the live env state (all device, caller-owned; belief may be NULL = no belief) */
+typedef struct sy_env_state {
+    int32_t *pos;
+    int32_t *budget;
+    int32_t *t;
+    uint32_t *step_count;
+    uint16_t *visits;
+    float *belief;
+    uint8_t *mask;
+    double *reward;
+    uint8_t *terminated;
+    uint8_t *truncated;
+    int8_t *winner;
+} sy_env_state;
+
+/* rollout record, leading dims [T][B]; any member may be NULL to skip it (all device).
+ * Row s holds the observation BEFORE step s, the action taken, and that step's outcome. */
+typedef struct sy_rollout_buffers {
+    int32_t *pos;        /* [T][B][A]     */
+    int32_t *budget;     /* [T][B][A]     */
+    int32_t *t;          /* [T][B]        */
+    int32_t *action;     /* [T][B][A]     */
+    uint8_t *mask;       /* [T][B][A][NS] */
+    float *belief;       /* [T][B][NS]    */
+    double *reward;      /* [T][B][A]     */
+    uint8_t *terminated; /* [T][B]        */
+    uint8_t *truncated;  /* [T][B]        */
+    int8_t *winner;      /* [T][B]        */
+} sy_rollout_buffers;
+
+int sy_abi_version(void);
+const char *sy_last_error(void);
+
+/* replaces CustomEnvironment.__init__ (yard.py:18-78) for a batch of B envs */
+int sy_env_create(const sy_env_config *cfg, sy_env **out);
+int sy_env_destroy(sy_env *env);
+/* LDS bytes and block count one engine launch uses (for DESIGN/bench reporting) */
+int sy_env_launch_info(const sy_env *env, int32_t *waves_per_block, int32_t *blocks, int32_t *lds_bytes);
+
+/* board + shortest-path tables (replaces board.edge_links/edges yard.py:91-93 and Pathfinder.set_board
+ * pathfinding.py:25-32); all device pointers */
+int sy_env_set_graph_pool(sy_env *env, const uint32_t *ell, const uint16_t *apsp, const float *inv_deg,
+                          const int32_t *env_graph);
+/* the 11 reward weights (host array, order = REWARD_WEIGHT_NAMES reward_net.py:5-17) and the device
+ * tables exp_tab[d] = exp(-d), cov_tab[v] = exp(-log1p(v)) (reward_calculator.py:184-207) */
+int sy_env_set_rewards(sy_env *env, const double *weights_host, const double *exp_tab, int32_t n_exp,
+                       const double *cov_tab, int32_t n_cov);
+int sy_env_bind_state(sy_env *env, const sy_env_state *state);
+
+/* replaces CustomEnvironment.reset (yard.py:80-142): distinct uniform start nodes from the engine's
+ * Philox stream, budgets [1000, money...], t = 0, visit counts cleared, belief re-initialised, masks.
+ * env_sel: device uint8[B] (NULL = all envs, which also zeroes step_count). */
+int sy_env_reset(sy_env *env, const uint8_t *env_sel, uint64_t seed, void *stream);
+/* same with caller-given start nodes, device int32[B][A] (golden replays) */
+int sy_env_reset_to(sy_env *env, const int32_t *starts, void *stream);
+
+/* replaces CustomEnvironment.step (yard.py:144-269): actions device int32[B][A], node id or -1 */
+int sy_env_step(sy_env *env, const int32_t *actions, void *stream);
+
+/* replaces the rollout loop (mappo_trainer.py:161-287) with the uniform-random policy
+ * (random_agent.py): T fused steps in ONE launch, records into `out` (may be NULL) */
+int sy_env_rollout(sy_env *env, int32_t T, const sy_rollout_buffers *out, void *stream);
+
+/* replaces compute_action_mask (action_mask.py:30-84), batched over Q queries on dense float64
+ * matrices (device; edge_weights / tolls may be NULL): mask uint8[Q][N] */
+int sy_action_mask_dense(const double *adjacency, const double *edge_weights, const double *tolls,
+                         int32_t num_nodes, const int32_t *current_node, const double *budget,
+                         int32_t num_queries, uint8_t *mask, void *stream);
+
+/* replaces ParticleBeliefTracker.update (belief_module.py:69-111) with its deterministic forward
+ * filter, batched: belief float[Q][NS] in/out; hint int32[Q][H] (-1 padded, NULL = none);
+ * reveal int32[Q] (-1 = none, NULL = none); ell/inv_deg of ONE graph */
+int sy_belief_update(const uint32_t *ell, const float *inv_deg, int32_t num_nodes, int32_t node_stride,
+                     float *belief, const int32_t *hint, int32_t hint_width, const int32_t *reveal,
+                     int32_t num_queries, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

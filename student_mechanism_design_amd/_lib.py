@@ -1,0 +1,84 @@
+"""ctypes binding of the C ABI in include/sy_env.h.  There is NO fallback path: if the HIP library
+is missing or a call fails, this module raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsy_env.so")
+
+ELL_WIDTH = 16
+MAX_AGENTS = 8
+MAX_NODES = 1024
+NUM_WEIGHTS = 11
+MRX_MONEY = 1000
+ABI_VERSION = 1
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class EnvConfig(C.Structure):
+    _fields_ = [("num_envs", C.c_int32), ("num_nodes", C.c_int32), ("num_police", C.c_int32),
+                ("agent_money", C.c_int32), ("max_timestep", C.c_int32), ("num_graphs", C.c_int32),
+                ("node_stride", C.c_int32), ("reveal_interval", C.c_int32), ("police_evidence", C.c_int32),
+                ("belief_init_onehot", C.c_int32), ("auto_reset", C.c_int32), ("waves_per_block", C.c_int32),
+                ("env_id_offset", C.c_uint64)]
+
+
+class EnvState(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("pos", "budget", "t", "step_count", "visits", "belief", "mask",
+                                          "reward", "terminated", "truncated", "winner")]
+
+
+class RolloutBuffers(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("pos", "budget", "t", "action", "mask", "belief", "reward",
+                                          "terminated", "truncated", "winner")]
+
+
+EXPORTS = ["sy_abi_version", "sy_last_error", "sy_env_create", "sy_env_destroy", "sy_env_launch_info",
+           "sy_env_set_graph_pool", "sy_env_set_rewards", "sy_env_bind_state", "sy_env_reset", "sy_env_reset_to",
+           "sy_env_step", "sy_env_rollout", "sy_action_mask_dense", "sy_belief_update"]
+
+_lib = None
+
+
+def load():
+    """Load libsy_env.so (built by student_mechanism_design_amd.build).  Raises if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineError(
+            f"HIP engine library not found at {LIB_PATH}. Build it with "
+            "`python -m student_mechanism_design_amd.build` (needs hipcc); there is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, u64 = C.c_void_p, C.c_int32, C.c_uint64
+    lib.sy_abi_version.restype = C.c_int
+    lib.sy_last_error.restype = C.c_char_p
+    lib.sy_env_create.argtypes = [C.POINTER(EnvConfig), C.POINTER(vp)]
+    lib.sy_env_destroy.argtypes = [vp]
+    lib.sy_env_launch_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    lib.sy_env_set_graph_pool.argtypes = [vp, vp, vp, vp, vp]
+    lib.sy_env_set_rewards.argtypes = [vp, C.POINTER(C.c_double), vp, i32, vp, i32]
+    lib.sy_env_bind_state.argtypes = [vp, C.POINTER(EnvState)]
+    lib.sy_env_reset.argtypes = [vp, vp, u64, vp]
+    lib.sy_env_reset_to.argtypes = [vp, vp, vp]
+    lib.sy_env_step.argtypes = [vp, vp, vp]
+    lib.sy_env_rollout.argtypes = [vp, i32, C.POINTER(RolloutBuffers), vp]
+    lib.sy_action_mask_dense.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp]
+    lib.sy_belief_update.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, i32, vp]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("sy_last_error",):
+            fn.restype = C.c_int
+    if lib.sy_abi_version() != ABI_VERSION:
+        raise EngineError(f"libsy_env.so ABI {lib.sy_abi_version()} != expected {ABI_VERSION}; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().sy_last_error().decode("utf-8", "replace")
+        raise EngineError(f"{what} failed ({rc}): {msg}")

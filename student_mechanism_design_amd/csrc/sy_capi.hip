@@ -1,0 +1,212 @@
+// sy_capi.hip — the C ABI declared in include/sy_env.h (no torch, no C++ types across the boundary).
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "sy_kernels.h"
+
+struct sy_env {
+    sy_env_config cfg;
+    sy::EngineParams p;
+    bool has_graph, has_rewards, has_state;
+    int wpb, blocks;
+    size_t lds;
+};
+
+namespace {
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, const char* a = "", long long x = 0, long long y = 0) {
+    std::snprintf(g_err, sizeof(g_err), fmt, a, x, y);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+    std::snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return SY_ERR_HIP;
+}
+
+constexpr size_t kMaxLds = 160 * 1024;
+}  // namespace
+
+extern "C" {
+
+int sy_abi_version(void) { return SY_ABI_VERSION; }
+const char* sy_last_error(void) { return g_err; }
+
+int sy_env_create(const sy_env_config* c, sy_env** out) {
+    if (!c || !out) return fail(SY_ERR_INVALID, "sy_env_create: null argument%s");
+    *out = nullptr;
+    if (c->num_envs <= 0) return fail(SY_ERR_INVALID, "num_envs must be > 0%s");
+    if (c->num_police < 1 || c->num_police + 1 > SY_MAX_AGENTS)
+        return fail(SY_ERR_INVALID, "num_police must be in [1, %s%lld]", "", SY_MAX_AGENTS - 1);
+    if (c->num_nodes < c->num_police + 1 || c->num_nodes > SY_MAX_NODES)
+        return fail(SY_ERR_INVALID, "num_nodes must be in [num_police+1, %s%lld]", "", SY_MAX_NODES);
+    if (c->node_stride < c->num_nodes || (c->node_stride & 15))
+        return fail(SY_ERR_INVALID, "node_stride must be a multiple of 16 and >= num_nodes%s");
+    if (c->num_graphs < 1) return fail(SY_ERR_INVALID, "num_graphs must be >= 1%s");
+    if (c->agent_money < 0 || c->agent_money > 0xffff)
+        return fail(SY_ERR_INVALID, "agent_money must be in [0, 65535]%s");
+    if (c->max_timestep < 0) return fail(SY_ERR_INVALID, "max_timestep must be >= 0%s");
+    if (c->reveal_interval < 0) return fail(SY_ERR_INVALID, "reveal_interval must be >= 0%s");
+    if (c->waves_per_block < 0 || c->waves_per_block > 16)
+        return fail(SY_ERR_INVALID, "waves_per_block must be in [0, 16]%s");
+    sy_env* e = new (std::nothrow) sy_env();
+    if (!e) return fail(SY_ERR_INVALID, "out of host memory%s");
+    std::memset(e, 0, sizeof(*e));
+    e->cfg = *c;
+    sy::EngineParams& p = e->p;
+    p.B = c->num_envs;
+    p.N = c->num_nodes;
+    p.NS = c->node_stride;
+    p.P = c->num_police;
+    p.A = c->num_police + 1;
+    p.G = c->num_graphs;
+    p.money0 = c->agent_money;
+    p.max_t = c->max_timestep;
+    p.reveal_k = c->reveal_interval;
+    p.police_ev = c->police_evidence ? 1 : 0;
+    p.belief_onehot = c->belief_init_onehot ? 1 : 0;
+    p.auto_reset = c->auto_reset ? 1 : 0;
+    p.env_id_offset = c->env_id_offset;
+    p.wave_lds_bytes = (p.NS + 16) * 4 + p.A * p.NS + p.NS * 2;
+    const size_t ell_bytes = (size_t)p.N * SY_ELL_WIDTH * 4;
+    int wpb = c->waves_per_block ? c->waves_per_block : 8;
+    while (wpb > 1 && ell_bytes + (size_t)wpb * p.wave_lds_bytes > kMaxLds) --wpb;
+    if (ell_bytes + (size_t)wpb * p.wave_lds_bytes > kMaxLds) {
+        delete e;
+        return fail(SY_ERR_INVALID, "board does not fit in LDS%s");
+    }
+    e->wpb = wpb;
+    e->blocks = (p.B + wpb - 1) / wpb;
+    e->lds = ell_bytes + (size_t)wpb * p.wave_lds_bytes;
+    *out = e;
+    return SY_OK;
+}
+
+int sy_env_destroy(sy_env* env) {
+    delete env;
+    return SY_OK;
+}
+
+int sy_env_launch_info(const sy_env* env, int32_t* wpb, int32_t* blocks, int32_t* lds_bytes) {
+    if (!env) return fail(SY_ERR_INVALID, "null env%s");
+    if (wpb) *wpb = env->wpb;
+    if (blocks) *blocks = env->blocks;
+    if (lds_bytes) *lds_bytes = (int32_t)env->lds;
+    return SY_OK;
+}
+
+int sy_env_set_graph_pool(sy_env* env, const uint32_t* ell, const uint16_t* apsp, const float* inv_deg,
+                          const int32_t* env_graph) {
+    if (!env || !ell || !apsp || !inv_deg || !env_graph) return fail(SY_ERR_INVALID, "sy_env_set_graph_pool: null argument%s");
+    if ((reinterpret_cast<uintptr_t>(ell) & 15)) return fail(SY_ERR_INVALID, "ell must be 16-byte aligned%s");
+    env->p.ell = ell;
+    env->p.apsp = apsp;
+    env->p.inv_deg = inv_deg;
+    env->p.env_graph = env_graph;
+    env->has_graph = true;
+    return SY_OK;
+}
+
+int sy_env_set_rewards(sy_env* env, const double* w, const double* exp_tab, int32_t n_exp, const double* cov_tab,
+                       int32_t n_cov) {
+    if (!env || !w || !exp_tab || !cov_tab) return fail(SY_ERR_INVALID, "sy_env_set_rewards: null argument%s");
+    if (n_exp < 1 || n_cov < 1) return fail(SY_ERR_INVALID, "reward tables must not be empty%s");
+    for (int i = 0; i < SY_NUM_WEIGHTS; ++i) env->p.w[i] = w[i];
+    env->p.exp_tab = exp_tab;
+    env->p.cov_tab = cov_tab;
+    env->p.n_exp = n_exp;
+    env->p.n_cov = n_cov;
+    env->has_rewards = true;
+    return SY_OK;
+}
+
+int sy_env_bind_state(sy_env* env, const sy_env_state* s) {
+    if (!env || !s) return fail(SY_ERR_INVALID, "sy_env_bind_state: null argument%s");
+    if (!s->pos || !s->budget || !s->t || !s->step_count || !s->visits || !s->mask || !s->reward || !s->terminated ||
+        !s->truncated || !s->winner)
+        return fail(SY_ERR_INVALID, "sy_env_bind_state: only `belief` may be NULL%s");
+    if ((reinterpret_cast<uintptr_t>(s->mask) & 15) || (reinterpret_cast<uintptr_t>(s->visits) & 15))
+        return fail(SY_ERR_INVALID, "mask and visits must be 16-byte aligned%s");
+    env->p.st = *s;
+    env->has_state = true;
+    return SY_OK;
+}
+
+static int ready(const sy_env* env, const char* who) {
+    if (!env) return fail(SY_ERR_INVALID, "%s: null env", who);
+    if (!env->has_graph) return fail(SY_ERR_STATE, "%s: call sy_env_set_graph_pool first", who);
+    if (!env->has_state) return fail(SY_ERR_STATE, "%s: call sy_env_bind_state first", who);
+    return SY_OK;
+}
+
+int sy_env_reset(sy_env* env, const uint8_t* env_sel, uint64_t seed, void* stream) {
+    int rc = ready(env, "sy_env_reset");
+    if (rc) return rc;
+    env->p.seed_lo = (uint32_t)seed;
+    env->p.seed_hi = (uint32_t)(seed >> 32);
+    hipError_t e = sy::launch_reset(env->p, env_sel, nullptr, env_sel ? 0 : 1, env->blocks, env->wpb * 64, env->lds,
+                                    (hipStream_t)stream);
+    return e == hipSuccess ? SY_OK : hip_fail(e, "sy_env_reset launch");
+}
+
+int sy_env_reset_to(sy_env* env, const int32_t* starts, void* stream) {
+    int rc = ready(env, "sy_env_reset_to");
+    if (rc) return rc;
+    if (!starts) return fail(SY_ERR_INVALID, "sy_env_reset_to: null starts%s");
+    hipError_t e = sy::launch_reset(env->p, nullptr, starts, 1, env->blocks, env->wpb * 64, env->lds, (hipStream_t)stream);
+    return e == hipSuccess ? SY_OK : hip_fail(e, "sy_env_reset_to launch");
+}
+
+int sy_env_step(sy_env* env, const int32_t* actions, void* stream) {
+    int rc = ready(env, "sy_env_step");
+    if (rc) return rc;
+    if (!env->has_rewards) return fail(SY_ERR_STATE, "%s: call sy_env_set_rewards first", "sy_env_step");
+    if (!actions) return fail(SY_ERR_INVALID, "sy_env_step: null actions%s");
+    sy_rollout_buffers none;
+    std::memset(&none, 0, sizeof(none));
+    hipError_t e = sy::launch_engine(env->p, actions, 1, none, true, env->blocks, env->wpb * 64, env->lds, (hipStream_t)stream);
+    return e == hipSuccess ? SY_OK : hip_fail(e, "sy_env_step launch");
+}
+
+int sy_env_rollout(sy_env* env, int32_t T, const sy_rollout_buffers* out, void* stream) {
+    int rc = ready(env, "sy_env_rollout");
+    if (rc) return rc;
+    if (!env->has_rewards) return fail(SY_ERR_STATE, "%s: call sy_env_set_rewards first", "sy_env_rollout");
+    if (T < 1) return fail(SY_ERR_INVALID, "sy_env_rollout: T must be >= 1%s");
+    sy_rollout_buffers o;
+    if (out) o = *out;
+    else std::memset(&o, 0, sizeof(o));
+    if (o.mask && (reinterpret_cast<uintptr_t>(o.mask) & 15)) return fail(SY_ERR_INVALID, "rollout mask must be 16-byte aligned%s");
+    hipError_t e = sy::launch_engine(env->p, nullptr, T, o, false, env->blocks, env->wpb * 64, env->lds, (hipStream_t)stream);
+    return e == hipSuccess ? SY_OK : hip_fail(e, "sy_env_rollout launch");
+}
+
+int sy_action_mask_dense(const double* adjacency, const double* edge_weights, const double* tolls, int32_t num_nodes,
+                         const int32_t* current_node, const double* budget, int32_t num_queries, uint8_t* mask,
+                         void* stream) {
+    if (!adjacency || !current_node || !budget || !mask) return fail(SY_ERR_INVALID, "sy_action_mask_dense: null argument%s");
+    if (num_nodes < 1 || num_queries < 0) return fail(SY_ERR_INVALID, "sy_action_mask_dense: bad sizes%s");
+    if (num_queries == 0) return SY_OK;
+    hipError_t e = sy::launch_action_mask_dense(adjacency, edge_weights, tolls, num_nodes, current_node, budget, num_queries,
+                                                mask, (hipStream_t)stream);
+    return e == hipSuccess ? SY_OK : hip_fail(e, "sy_action_mask_dense launch");
+}
+
+int sy_belief_update(const uint32_t* ell, const float* inv_deg, int32_t num_nodes, int32_t node_stride, float* belief,
+                     const int32_t* hint, int32_t hint_width, const int32_t* reveal, int32_t num_queries, void* stream) {
+    if (!ell || !inv_deg || !belief) return fail(SY_ERR_INVALID, "sy_belief_update: null argument%s");
+    if (num_nodes < 1 || num_nodes > SY_MAX_NODES || node_stride < num_nodes || (node_stride & 15))
+        return fail(SY_ERR_INVALID, "sy_belief_update: bad num_nodes / node_stride%s");
+    if (hint && hint_width < 1) return fail(SY_ERR_INVALID, "sy_belief_update: hint_width must be >= 1%s");
+    if (num_queries < 0) return fail(SY_ERR_INVALID, "sy_belief_update: bad num_queries%s");
+    if (num_queries == 0) return SY_OK;
+    hipError_t e = sy::launch_belief_update(ell, inv_deg, num_nodes, node_stride, belief, hint, hint ? hint_width : 0, reveal,
+                                            num_queries, (hipStream_t)stream);
+    return e == hipSuccess ? SY_OK : hip_fail(e, "sy_belief_update launch");
+}
+
+}  // extern "C"

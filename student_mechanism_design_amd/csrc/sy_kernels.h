@@ -1,0 +1,37 @@
+// sy_kernels.h — internal interface between the C ABI (sy_capi.hip) and the kernels (sy_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sy_env.h"
+
+namespace sy {
+
+// Passed by value to every engine launch (kernel-argument segment, scalar loads).
+struct EngineParams {
+    int32_t B, N, NS, P, A, G;
+    int32_t money0, max_t, reveal_k, police_ev, belief_onehot, auto_reset;
+    int32_t wave_lds_bytes;       // private LDS slice per wave (belief scratch + mask rows + visits)
+    uint32_t seed_lo, seed_hi;    // Philox key
+    uint64_t env_id_offset;
+    const uint32_t* ell;          // [G][N][16]
+    const uint16_t* apsp;         // [G][N][N]
+    const float* inv_deg;         // [G][NS]
+    const int32_t* env_graph;     // [B]
+    double w[SY_NUM_WEIGHTS];
+    const double* exp_tab;
+    const double* cov_tab;
+    int32_t n_exp, n_cov;
+    sy_env_state st;
+};
+
+hipError_t launch_engine(const EngineParams& p, const int32_t* actions, int T, const sy_rollout_buffers& out, bool ext,
+                         int blocks, int threads, size_t lds, hipStream_t stream);
+hipError_t launch_reset(const EngineParams& p, const uint8_t* env_sel, const int32_t* starts, int zero_count, int blocks,
+                        int threads, size_t lds, hipStream_t stream);
+hipError_t launch_action_mask_dense(const double* adj, const double* wts, const double* tolls, int N, const int32_t* cur,
+                                    const double* budget, int Q, uint8_t* mask, hipStream_t stream);
+hipError_t launch_belief_update(const uint32_t* ell, const float* inv_deg, int N, int NS, float* belief, const int32_t* hint,
+                                int H, const int32_t* reveal, int Q, hipStream_t stream);
+
+}  // namespace sy

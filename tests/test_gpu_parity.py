@@ -1,0 +1,315 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle and the golden traces.
+
+Bit-exact: positions, budgets, masks, flags, winner, visit counts, timesteps, sampled actions.
+Rewards: float64, bit-exact against the oracle when both use the same exp/coverage tables
+(the engine keeps the reference's operation order); 1e-12 against the reference goldens.
+Belief: float32 on device vs float64 oracle, absolute tolerance 1e-5 (BASELINE.json north_star).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from tests.helpers import GOLDEN, engine_actions, load_trace, trace_index  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+BELIEF_TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def sy():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import student_mechanism_design_amd as sy_mod
+    sy_mod._lib.load()  # fail loudly if the HIP library is missing
+    return sy_mod
+
+
+@pytest.fixture(scope="module")
+def ol():
+    from oracle import oracle_lib
+    oracle_lib.load()
+    return oracle_lib
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+# ----------------------------------------------------------------------------------------------
+# golden traces recorded from the unmodified reference
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", [e["file"] for e in trace_index()])
+def test_golden_trace_on_device(sy, name):
+    tr = load_trace(name)
+    N, P, A = int(tr["N"]), int(tr["P"]), int(tr["P"]) + 1
+    board = sy.make_board(N, tr["edge_links"], tr["edge_w"])
+    B = 5  # the same episode on several waves (incl. a partial launch block)
+    env = sy.BatchedScotlandYardEnv(B, [board], P, int(tr["money0"]), tr["weights"], auto_reset=False,
+                                    waves_per_block=4)
+    env.reset_to(np.tile(tr["starts"], (B, 1)))
+    np.testing.assert_array_equal(_np(env.action_mask), np.tile(tr["mask0"], (B, 1, 1)))
+    T = tr["actions"].shape[0]
+    for s in range(T):
+        act = np.tile(engine_actions(tr["actions"][s]), (B, 1))
+        env.step(torch.as_tensor(act, dtype=torch.int32, device=env.device))
+        for b in (0, B - 1):
+            np.testing.assert_array_equal(_np(env.pos)[b], tr["pos"][s], err_msg=f"pos step {s}")
+            np.testing.assert_array_equal(_np(env.budget)[b], tr["money"][s], err_msg=f"money step {s}")
+            assert bool(_np(env.terminated)[b]) == bool(tr["terminated"][s]), f"terminated step {s}"
+            assert bool(_np(env.truncated)[b]) == bool(tr["truncated"][s]), f"truncated step {s}"
+            assert int(_np(env.winner)[b]) == int(tr["winner"][s]), f"winner step {s}"
+            assert int(_np(env.t)[b]) == int(tr["t_after"][s])
+            np.testing.assert_array_equal(_np(env.visits)[b].astype(np.int32), tr["visits"][s], err_msg=f"visits {s}")
+            np.testing.assert_array_equal(_np(env.action_mask)[b], tr["masks"][s], err_msg=f"masks step {s}")
+            np.testing.assert_allclose(_np(env.reward)[b], tr["reward"][s], rtol=1e-12, atol=1e-12,
+                                       err_msg=f"reward step {s}")
+    env.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# engine vs oracle on seeded random inputs
+# ----------------------------------------------------------------------------------------------
+def _make_pair(sy, ol, B, N, E, P, money, G, seed, **kw):
+    boards = sy.sample_board_pool(G, N, E, seed=seed)
+    rng = np.random.default_rng(seed)
+    weights = rng.uniform(0.05, 0.95, 11)
+    env = sy.BatchedScotlandYardEnv(B, boards, P, money, weights, seed=seed, **kw)
+    graphs = [ol.OracleGraph(N, b.edge_links, b.edges.astype(np.int32)) for b in boards]
+    tables = sy.reward_tables()
+    okw = {k: v for k, v in kw.items() if k in ("reveal_interval", "police_evidence", "belief_init_onehot",
+                                                "auto_reset", "env_id_offset", "max_t")}
+    if "max_timestep" in kw:
+        okw["max_t"] = kw["max_timestep"]
+    orc = ol.OracleBatch(graphs, env.env_graph_host, B, P, money, node_stride=env.NS, weights=weights,
+                         tables=tables, **okw)
+    orc.reset(seed=seed)
+    return env, orc, boards
+
+
+def _compare_state(env, orc, what=""):
+    N = env.N
+    np.testing.assert_array_equal(_np(env.pos), orc.pos, err_msg=f"pos {what}")
+    np.testing.assert_array_equal(_np(env.budget), orc.money, err_msg=f"budget {what}")
+    np.testing.assert_array_equal(_np(env.t), orc.t, err_msg=f"t {what}")
+    np.testing.assert_array_equal(_np(env.step_count).astype(np.uint32), orc.step_count, err_msg=f"step_count {what}")
+    np.testing.assert_array_equal(_np(env.visits).astype(np.int32), orc.visits[:, :N], err_msg=f"visits {what}")
+    np.testing.assert_array_equal(_np(env._mask), orc.mask, err_msg=f"mask {what}")
+    np.testing.assert_array_equal(_np(env._terminated), orc.terminated, err_msg=f"terminated {what}")
+    np.testing.assert_array_equal(_np(env._truncated), orc.truncated, err_msg=f"truncated {what}")
+    np.testing.assert_array_equal(_np(env.winner), orc.winner, err_msg=f"winner {what}")
+    np.testing.assert_array_equal(_np(env.reward), orc.reward, err_msg=f"reward {what}")  # bit-exact float64
+    if env.belief is not None:
+        np.testing.assert_allclose(_np(env.belief), orc.belief[:, :N], rtol=0, atol=BELIEF_TOL, err_msg=f"belief {what}")
+
+
+def _random_actions(rng, env_pos, mask, N):
+    """Mostly legal moves, some no-ops / illegal / occupied targets."""
+    B, A = env_pos.shape
+    act = np.full((B, A), -1, dtype=np.int32)
+    u = rng.random((B, A))
+    for b in range(B):
+        for a in range(A):
+            legal = np.nonzero(mask[b, a])[0]
+            if u[b, a] < 0.7 and legal.size:
+                act[b, a] = rng.choice(legal)
+            elif u[b, a] < 0.8:
+                act[b, a] = -1
+            elif u[b, a] < 0.9:
+                act[b, a] = rng.integers(0, N + 3)
+            else:
+                act[b, a] = env_pos[b, rng.integers(0, A)]
+    return act
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=64, N=200, E=400, P=4, money=20, G=2, seed=1, reveal_interval=5),
+    dict(B=37, N=15, E=20, P=2, money=10, G=1, seed=2, police_evidence=True),
+    dict(B=48, N=64, E=110, P=6, money=8, G=3, seed=3, reveal_interval=3, belief_init_onehot=True, max_timestep=20),
+    dict(B=20, N=8, E=10, P=5, money=5, G=1, seed=4, auto_reset=False),
+    dict(B=16, N=300, E=560, P=7, money=30, G=1, seed=5, reveal_interval=7, police_evidence=True),
+])
+def test_step_matches_oracle(sy, ol, cfg):
+    cfg = dict(cfg)
+    B, N, E, P, money, G, seed = (cfg.pop(k) for k in ("B", "N", "E", "P", "money", "G", "seed"))
+    env, orc, _ = _make_pair(sy, ol, B, N, E, P, money, G, seed, **cfg)
+    _compare_state(env, orc, "after reset")
+    rng = np.random.default_rng(100 + seed)
+    for s in range(120):
+        act = _random_actions(rng, orc.pos, orc.mask[:, :, :N], N)
+        env.step(torch.as_tensor(act, device=env.device))
+        orc.step(act)
+        _compare_state(env, orc, f"step {s}")
+    env.close()
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(B=128, N=200, E=400, P=4, money=20, G=4, seed=11, reveal_interval=5, T=96),
+    dict(B=33, N=15, E=20, P=2, money=10, G=1, seed=12, T=300),
+    dict(B=40, N=100, E=190, P=6, money=6, G=2, seed=13, police_evidence=True, reveal_interval=4, T=80),
+    dict(B=24, N=40, E=70, P=3, money=50, G=1, seed=14, max_timestep=30, T=200),
+])
+def test_fused_rollout_matches_oracle(sy, ol, cfg):
+    cfg = dict(cfg)
+    B, N, E, P, money, G, seed, T = (cfg.pop(k) for k in ("B", "N", "E", "P", "money", "G", "seed", "T"))
+    env, orc, _ = _make_pair(sy, ol, B, N, E, P, money, G, seed, **cfg)
+    rec = env.rollout(T)
+    ref = orc.rollout(T)
+    for k in ("pos", "t", "action", "terminated", "truncated", "winner", "mask", "reward"):
+        np.testing.assert_array_equal(_np(rec[k]), ref[k], err_msg=k)
+    np.testing.assert_array_equal(_np(rec["budget"]), ref["money"], err_msg="budget")
+    np.testing.assert_allclose(_np(rec["belief"]), ref["belief"], rtol=0, atol=BELIEF_TOL)
+    _compare_state(env, orc, "after rollout")
+    done = ref["terminated"] | ref["truncated"]
+    assert done.any(), "the case must contain finished episodes (auto-reset path)"
+    # a second rollout continues from the live state
+    rec2 = env.rollout(7)
+    ref2 = orc.rollout(7)
+    np.testing.assert_array_equal(_np(rec2["action"]), ref2["action"])
+    np.testing.assert_array_equal(_np(rec2["pos"]), ref2["pos"])
+    env.close()
+
+
+def test_rollout_equals_stepping_its_own_actions(sy):
+    """Fused sampling path == caller-action path: replaying the recorded actions through step()."""
+    boards = sy.sample_board_pool(2, 60, 100, seed=21)
+    w = np.linspace(0.1, 0.9, 11)
+    a = sy.BatchedScotlandYardEnv(64, boards, 4, 12, w, seed=5, reveal_interval=5)
+    b = sy.BatchedScotlandYardEnv(64, boards, 4, 12, w, seed=5, reveal_interval=5)
+    rec = a.rollout(50)
+    for s in range(50):
+        np.testing.assert_array_equal(_np(b.pos), _np(rec["pos"][s]))
+        np.testing.assert_array_equal(_np(b._mask), _np(rec["mask"][s]))
+        np.testing.assert_array_equal(_np(b._belief), _np(rec["belief"][s]))
+        b.step(rec["action"][s].contiguous())
+        np.testing.assert_array_equal(_np(b.reward), _np(rec["reward"][s]))
+        np.testing.assert_array_equal(_np(b._terminated), _np(rec["terminated"][s]))
+    np.testing.assert_array_equal(_np(a.pos), _np(b.pos))
+    a.close()
+    b.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# BASELINE.json full size (N=200, P=4, B=4096): size-independent properties
+# ----------------------------------------------------------------------------------------------
+def test_full_size_properties(sy):
+    N, E, P, B, T = 200, 400, 4, 4096, 64
+    boards = sy.sample_board_pool(8, N, E, seed=7)
+    env = sy.BatchedScotlandYardEnv(B, boards, P, 20, np.full(11, 0.5), seed=3, reveal_interval=5)
+    rec = env.rollout(T)
+    pos, bud, act = _np(rec["pos"]), _np(rec["budget"]), _np(rec["action"])
+    mask, bel = _np(rec["mask"])[..., :N].astype(bool), _np(rec["belief"])[..., :N]
+    done = (_np(rec["terminated"]) | _np(rec["truncated"])).astype(bool)
+    # agents never share a node before a step; MrX's budget is constant
+    srt = np.sort(pos, axis=-1)
+    assert (np.diff(srt, axis=-1) > 0).all()
+    assert (bud[..., 0] == 1000).all() and (bud[..., 1:] >= 0).all() and (bud[..., 1:] <= 20).all()
+    # every sampled action is legal under the recorded mask (or -1 with an empty mask)
+    tt, bb, aa = np.nonzero(act >= 0)
+    assert mask[tt, bb, aa, act[tt, bb, aa]].all()
+    assert (mask.sum(-1)[act < 0] == 0).all()
+    # masks = affordable ELL neighbours of the recorded position
+    ell = env.pool.ell
+    g = env.env_graph_host
+    for t_ in (0, T // 2, T - 1):
+        for b_ in (0, 1, 2047, 4095):
+            for a_ in range(P + 1):
+                row = ell[g[b_], pos[t_, b_, a_]]
+                nb, w = row & 0xFFFF, row >> 16
+                legal = np.zeros(N, bool)
+                legal[nb[(nb < N) & (w <= bud[t_, b_, a_])]] = True
+                np.testing.assert_array_equal(mask[t_, b_, a_], legal)
+    # beliefs are distributions
+    np.testing.assert_allclose(bel.sum(-1), 1.0, atol=1e-4)
+    assert (bel >= 0).all()
+    # budgets never grow inside an episode; timestep advances by one or restarts at 0 after done
+    t_arr = _np(rec["t"])
+    cont = ~done[:-1]
+    assert (bud[1:][cont] <= bud[:-1][cont]).all()
+    assert (t_arr[1:][cont] == t_arr[:-1][cont] + 1).all()
+    assert (t_arr[1:][done[:-1]] == 0).all()
+    # fusing is idempotent: T steps in one launch == T launches of one step
+    env2 = sy.BatchedScotlandYardEnv(B, boards, P, 20, np.full(11, 0.5), seed=3, reveal_interval=5)
+    for _ in range(8):
+        env2.rollout(1, record=False)
+    env3 = sy.BatchedScotlandYardEnv(B, boards, P, 20, np.full(11, 0.5), seed=3, reveal_interval=5)
+    env3.rollout(8, record=False)
+    for name in ("pos", "budget", "t", "_mask", "_belief", "_visits", "reward"):
+        assert torch.equal(getattr(env2, name), getattr(env3, name)), name
+    # different seeds / env_id_offset give different streams
+    env4 = sy.BatchedScotlandYardEnv(B, boards, P, 20, np.full(11, 0.5), seed=3, env_id_offset=B)
+    env5 = sy.BatchedScotlandYardEnv(B, boards, P, 20, np.full(11, 0.5), seed=3)
+    env6 = sy.BatchedScotlandYardEnv(B, boards, P, 20, np.full(11, 0.5), seed=4)
+    assert not torch.equal(env4.pos, env5.pos) and not torch.equal(env6.pos, env5.pos)
+
+
+# ----------------------------------------------------------------------------------------------
+# action-mask known answers and belief filter through their own entry points
+# ----------------------------------------------------------------------------------------------
+def test_action_mask_known_answers_on_device(sy):
+    with open(os.path.join(GOLDEN, "action_mask_kats.json")) as f:
+        cases = json.load(f)
+    for c in cases:
+        tolls = c["tolls"]
+        if tolls is not None and not np.isscalar(tolls):
+            tolls = np.array(tolls)
+        w = None if c["edge_weights"] is None else np.array(c["edge_weights"], dtype=float)
+        r = sy.compute_action_mask(np.array(c["adjacency"], dtype=float), c["current_node"], c["budget"],
+                                   tolls=tolls, edge_weights=w)
+        np.testing.assert_array_equal(r.mask, np.array(c["mask"], dtype=bool), err_msg=c["tag"])
+        n = len(c["mask"])
+        assert r.index_to_node == {i: i for i in range(n)} and r.node_to_index == r.index_to_node
+        assert r.valid_actions == [i for i in range(n) if c["mask"][i]]
+        assert r.num_valid_actions == sum(c["mask"])
+
+
+def test_belief_tracker_on_device(sy, ol):
+    with open(os.path.join(GOLDEN, "belief_reference.json")) as f:
+        ref = json.load(f)
+    # the reference's own test scenario (test/test_belief_update.py)
+    adj = np.array(ref["ref_test"]["adjacency"])
+    tr = sy.DeviceBeliefTracker(3, adj)
+    b = _np(tr.update(adj, observation_hint=[1]))[0]
+    np.testing.assert_allclose(b, [1 / 42, 40 / 42, 1 / 42], atol=BELIEF_TOL)
+    assert np.isclose(b.sum(), 1.0)
+    b = _np(tr.update(adj, reveal=2))[0]
+    assert b.argmax() == 2 and np.isclose(b.sum(), 1.0)
+    # scripted scenarios vs the float64 oracle filter (itself pinned to the particle tracker)
+    for case in ref["monte_carlo"]:
+        adj = np.array(case["adjacency"])
+        n = adj.shape[0]
+        links = [(i, j) for i in range(n) for j in range(i + 1, n) if adj[i, j]]
+        g = ol.OracleGraph(n, np.array(links, np.int32).reshape(-1, 2), np.ones(len(links), np.int32))
+        tr = sy.DeviceBeliefTracker(n, adj, num_beliefs=3)
+        ob = np.full(n, 1.0 / n)
+        for st in case["steps"]:
+            if st["kind"] == "hint":
+                ob = ol.belief_update(g, ob, hint=st["hint"])
+                db = tr.update(observation_hint=st["hint"])
+            elif st["kind"] == "reveal":
+                ob = ol.belief_update(g, ob, reveal=st["reveal"])
+                db = tr.update(reveal=st["reveal"])
+            else:
+                ob = ol.belief_update(g, ob)
+                db = tr.update()
+            for q in range(3):
+                np.testing.assert_allclose(_np(db)[q], ob, atol=BELIEF_TOL)
+
+
+def test_errors_are_reported_not_thrown_across_the_abi(sy):
+    import ctypes as C
+    lib = sy._lib.load()
+    cfg = sy._lib.EnvConfig(0, 10, 2, 10, 250, 1, 16, 0, 0, 0, 1, 0, 0)
+    h = C.c_void_p()
+    assert lib.sy_env_create(C.byref(cfg), C.byref(h)) == -1
+    assert b"num_envs" in lib.sy_last_error()
+    cfg = sy._lib.EnvConfig(4, 10, 2, 10, 250, 1, 16, 0, 0, 0, 1, 0, 0)
+    assert lib.sy_env_create(C.byref(cfg), C.byref(h)) == 0
+    assert lib.sy_env_step(h, None, None) == -2  # graph pool / state not bound yet
+    assert lib.sy_env_destroy(h) == 0
+    with pytest.raises(ValueError):
+        sy.BatchedScotlandYardEnv(4, [sy.sample_board(10, 14, rng=np.random.default_rng(0))], 2, 10, np.zeros(5))

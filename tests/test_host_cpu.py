@@ -1,0 +1,176 @@
+"""CPU-side tests (no GPU): host graph packing vs the oracle, the C-ABI library's exports, and the
+loud-failure rule of the product path."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import student_mechanism_design_amd as sy
+from oracle import oracle_lib as ol
+from tests.helpers import load_trace, trace_index
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_sampler_follows_reference_statistics():
+    """graph_layout.py:9-52: connected, requested edge count, weights in 1..4, no duplicate edges,
+    extras respect the degree cap of 4 (tree edges may exceed it)."""
+    rng = np.random.default_rng(0)
+    for n, e in ((15, 20), (50, 110), (200, 400)):
+        b = sy.sample_board(n, e, rng=rng)
+        assert b.num_nodes == n and b.num_edges == e
+        assert b.edges.min() >= 1 and b.edges.max() <= 4
+        und = {tuple(sorted(x)) for x in b.edge_links.tolist()}
+        assert len(und) == e
+        d = sy.all_pairs_shortest_paths(b)  # raises if disconnected
+        assert d.shape == (n, n)
+        tree, extra = b.edge_links[: n - 1], b.edge_links[n - 1:]
+        deg = np.bincount(tree.reshape(-1), minlength=n)
+        for u, v in extra:
+            assert deg[u] < 4 and deg[v] < 4
+            deg[u] += 1
+            deg[v] += 1
+    tree_only = sy.sample_board(12, None, rng=rng)
+    assert tree_only.num_edges == 11
+
+
+def test_pool_has_a_common_edge_count():
+    boards = sy.sample_board_pool(5, 40, 70, seed=3)
+    assert len({b.num_edges for b in boards}) == 1
+    sat = sy.sample_board_pool(3, 30, 70, seed=1)  # unreachable request: first sample fixes the count
+    assert len({b.num_edges for b in sat}) == 1 and sat[0].num_edges < 70
+
+
+def test_ell_and_apsp_match_oracle_on_golden_boards():
+    for e in trace_index()[::3]:
+        tr = load_trace(e["file"])
+        n = int(tr["N"])
+        board = sy.make_board(n, tr["edge_links"], tr["edge_w"])
+        g = ol.OracleGraph(n, tr["edge_links"], tr["edge_w"])
+        np.testing.assert_array_equal(sy.all_pairs_shortest_paths(board).astype(np.int32), g.dist)
+        ell = sy.pack_ell(board)
+        for u in range(n):
+            nb, w = ell[u] & 0xFFFF, ell[u] >> 16
+            real = nb < n
+            nodes, wts = g.possible_moves(u, 10**6)
+            np.testing.assert_array_equal(nb[real], nodes)
+            np.testing.assert_array_equal(w[real], wts)
+            assert (nb[~real] == n).all() and (w[~real] == 0xFFFF).all()
+            assert (np.diff(nb[real].astype(np.int64)) > 0).all()
+
+
+def test_pack_rejects_bad_boards():
+    with pytest.raises(ValueError):
+        sy.make_board(4, [[0, 0]], [1])
+    with pytest.raises(ValueError):
+        sy.make_board(4, [[0, 7]], [1])
+    star = sy.make_board(20, [[0, i] for i in range(1, 19)], np.ones(18))
+    with pytest.raises(ValueError):
+        sy.pack_ell(star)  # 18 neighbours > ELL width 16
+    with pytest.raises(ValueError):
+        sy.all_pairs_shortest_paths(sy.make_board(4, [[0, 1]], [1]))  # disconnected
+    dup = sy.make_board(3, [[0, 1], [1, 0], [1, 2]], [3, 2, 1])  # parallel edges -> cheapest
+    assert (sy.pack_ell(dup)[0, 0] >> 16) == 2
+
+
+def test_reward_tables_are_the_reference_formulas():
+    e, c = sy.reward_tables()
+    assert e[0] == 1.0 and e[3] == np.exp(-3.0) and c[0] == 1.0
+    assert c[4] == np.exp(-np.log1p(4))
+    oe, oc = ol.default_tables(64, 64)
+    np.testing.assert_allclose(e[:64], oe, rtol=1e-15)
+    np.testing.assert_allclose(c[:64], oc, rtol=1e-15)
+
+
+def test_capi_library_exports_every_declared_symbol():
+    """include/sy_env.h is the contract: every `int sy_*(`/`const char *sy_*(` must be exported."""
+    with open(os.path.join(ROOT, "include", "sy_env.h")) as f:
+        header = f.read()
+    declared = set(re.findall(r"^(?:int|const char \*)\s*(sy_[a-z_0-9]+)\s*\(", header, flags=re.M))
+    assert declared == set(sy._lib.EXPORTS), declared ^ set(sy._lib.EXPORTS)
+    assert os.path.exists(sy.LIB_PATH), "build the engine first: python -m student_mechanism_design_amd.build"
+    lib = C.CDLL(sy.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    lib.sy_abi_version.restype = C.c_int
+    assert lib.sy_abi_version() == sy._lib.ABI_VERSION
+
+
+def test_capi_argument_validation_without_gpu():
+    """Pure host-side checks of the ABI (no kernel is launched)."""
+    lib = sy._lib.load()
+    h = C.c_void_p()
+    bad = [
+        sy._lib.EnvConfig(0, 10, 2, 10, 250, 1, 16, 0, 0, 0, 1, 0, 0),     # no envs
+        sy._lib.EnvConfig(4, 10, 8, 10, 250, 1, 16, 0, 0, 0, 1, 0, 0),     # too many police
+        sy._lib.EnvConfig(4, 10, 2, 10, 250, 1, 10, 0, 0, 0, 1, 0, 0),     # stride not multiple of 16
+        sy._lib.EnvConfig(4, 2000, 2, 10, 250, 1, 2000, 0, 0, 0, 1, 0, 0),  # too many nodes
+        sy._lib.EnvConfig(4, 10, 2, 10, 250, 0, 16, 0, 0, 0, 1, 0, 0),     # no graphs
+        sy._lib.EnvConfig(4, 10, 2, 10, 250, 1, 16, 0, 0, 0, 1, 17, 0),    # waves per block
+    ]
+    for cfg in bad:
+        assert lib.sy_env_create(C.byref(cfg), C.byref(h)) == -1
+        assert lib.sy_last_error()
+    ok = sy._lib.EnvConfig(4096, 200, 4, 20, 250, 1, 208, 5, 0, 0, 1, 0, 0)
+    assert lib.sy_env_create(C.byref(ok), C.byref(h)) == 0
+    wpb, blocks, lds = C.c_int32(), C.c_int32(), C.c_int32()
+    assert lib.sy_env_launch_info(h, C.byref(wpb), C.byref(blocks), C.byref(lds)) == 0
+    assert wpb.value * blocks.value >= 4096 and 0 < lds.value <= 160 * 1024
+    assert lib.sy_env_step(h, None, None) == -2       # call order error, not a crash
+    assert lib.sy_env_rollout(h, 4, None, None) == -2
+    assert lib.sy_env_destroy(h) == 0
+    assert lib.sy_action_mask_dense(None, None, None, 3, None, None, 1, None, None) == -1
+    assert lib.sy_belief_update(None, None, 3, 16, None, None, 0, None, 1, None) == -1
+
+
+def test_product_path_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    b = sy.sample_board(10, 14, rng=np.random.default_rng(0))
+    with pytest.raises(sy.EngineError):
+        sy.BatchedScotlandYardEnv(4, [b], 2, 10, np.full(11, 0.5))
+    with pytest.raises(sy.EngineError):
+        sy.compute_action_mask(np.ones((2, 2)) - np.eye(2), 0, 1.0)
+    with pytest.raises(sy.EngineError):
+        sy.DeviceBeliefTracker(3, np.ones((3, 3)) - np.eye(3))
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "student_mechanism_design_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h")):
+                with open(os.path.join(dirpath, fn)) as f:
+                    src = f.read()
+                assert "oracle_lib" not in src and "sy_oracle" not in src and "from oracle" not in src, fn
+
+
+def test_oracle_batch_engine_is_self_consistent():
+    """The oracle's batched engine (the GPU checker): rollout == manual stepping of its own actions,
+    and OpenMP threads do not change results."""
+    boards = sy.sample_board_pool(2, 30, 50, seed=5)
+    graphs = [ol.OracleGraph(30, b.edge_links, b.edges.astype(np.int32)) for b in boards]
+    eg = np.repeat([0, 1], 8).astype(np.int32)
+    w = np.linspace(0.2, 0.8, 11)
+    a = ol.OracleBatch(graphs, eg, 16, 3, 9, weights=w, reveal_interval=5, node_stride=32)
+    b = ol.OracleBatch(graphs, eg, 16, 3, 9, weights=w, reveal_interval=5, node_stride=32, threads=4)
+    a.reset(seed=9)
+    b.reset(seed=9)
+    ra = a.rollout(60)
+    rb = b.rollout(60)
+    for k in ra:
+        np.testing.assert_array_equal(ra[k], rb[k], err_msg=k)
+    c = ol.OracleBatch(graphs, eg, 16, 3, 9, weights=w, reveal_interval=5, node_stride=32)
+    c.reset(seed=9)
+    for s in range(60):
+        np.testing.assert_array_equal(c.pos, ra["pos"][s])
+        np.testing.assert_array_equal(c.mask, ra["mask"][s])
+        c.step(ra["action"][s])
+        np.testing.assert_array_equal(c.reward, ra["reward"][s])
+    assert (ra["terminated"] | ra["truncated"]).any()
+    # starts are distinct and in range after every (auto-)reset
+    srt = np.sort(ra["pos"], axis=-1)
+    assert (np.diff(srt, axis=-1) > 0).all() and srt.min() >= 0 and srt.max() < 30

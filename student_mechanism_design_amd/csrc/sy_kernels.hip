@@ -39,7 +39,7 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// Philox4x32-10 (Salmon et al. 2011), word 0 — identical to oracle/sy_oracle.c:syo_philox4x32.
+// Philox4x32-10 (Salmon et al. 2011), word 0 of the output block.
 __device__ __forceinline__ uint32_t philox_draw(uint64_t gid, uint32_t ctr, uint32_t purpose, uint32_t idx,
                                                 uint32_t k0, uint32_t k1) {
     uint32_t c0 = (uint32_t)gid, c1 = (uint32_t)(gid >> 32), c2 = ctr, c3 = (purpose << 8) | idx;

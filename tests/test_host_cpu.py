@@ -18,7 +18,7 @@ def test_sampler_follows_reference_statistics():
     """graph_layout.py:9-52: connected, requested edge count, weights in 1..4, no duplicate edges,
     extras respect the degree cap of 4 (tree edges may exceed it)."""
     rng = np.random.default_rng(0)
-    for n, e in ((15, 20), (50, 110), (200, 400)):
+    for n, e in ((15, 20), (50, 90), (200, 400)):
         b = sy.sample_board(n, e, rng=rng)
         assert b.num_nodes == n and b.num_edges == e
         assert b.edges.min() >= 1 and b.edges.max() <= 4

@@ -80,6 +80,8 @@ def main():
     ap.add_argument("--reveal", type=int, default=5)
     ap.add_argument("--wpb", type=int, default=0, help="waves (envs) per launch block, 0 = engine default")
     ap.add_argument("--no-record", action="store_true", help="do not write the trajectory (diagnostic only)")
+    ap.add_argument("--no-belief", action="store_true", help="diagnostic: engine without the belief filter")
+    ap.add_argument("--no-mask-record", action="store_true", help="diagnostic: do not record masks")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--step-api", action="store_true", help="also time the per-step sy_env_step launch path")
@@ -106,8 +108,9 @@ def main():
     boards = sy.sample_board_pool(args.graphs, N, args.edges, seed=0)   # same synthetic boards on all ranks
     weights = np.full(11, 0.5)
     env = sy.BatchedScotlandYardEnv(B, boards, P, args.money, weights, seed=1234, reveal_interval=args.reveal,
-                                    env_id_offset=rank * B, waves_per_block=args.wpb, device=device)
-    out = None if args.no_record else env.alloc_rollout(T)
+                                    env_id_offset=rank * B, waves_per_block=args.wpb, device=device,
+                                    with_belief=not args.no_belief)
+    out = None if args.no_record else env.alloc_rollout(T, record_mask=not args.no_mask_record)
 
     def one_step():
         env.rollout(T, out=out, record=not args.no_record)

@@ -59,7 +59,7 @@ typedef struct sy_env_config {
     int32_t num_envs;          /* B, envs on THIS GPU                                         */
     int32_t num_nodes;         /* N  (graph_nodes, yard.py:25,52)                             */
     int32_t num_police;        /* P  (`number_of_agents`, yard.py:20,33)                      */
-    int32_t agent_money;       /* police budget at reset (yard.py:21,117-119)                 */
+    int32_t agent_money;       /* police budget at reset, <= 65534 (yard.py:21,117-119)       */
     int32_t max_timestep;      /* truncation when t > max_timestep; reference: 250            */
     int32_t num_graphs;        /* G, graphs in the pool                                       */
     int32_t node_stride;       /* NS, multiple of 16, >= N                                    */
@@ -86,7 +86,7 @@ typedef struct sy_env_state {
     int8_t *winner;
 } sy_env_state;
 
-/* rollout record, leading dims [T][B]; any member may be NULL to skip it (all device).
+/* rollout record, leading dims [T][B] (all device); `mask` and `belief` may be NULL to skip them.
  * Row s holds the observation BEFORE step s, the action taken, and that step's outcome. */
 typedef struct sy_rollout_buffers {
     int32_t *pos;        /* [T][B][A]     */

@@ -284,11 +284,11 @@ void syo_belief_update(const syo_graph *g, double *b, const int32_t *hint, int32
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* Philox4x32-10 (Salmon et al. 2011) — the counter-based RNG the device engine also uses     */
+/* Philox4x32-7 (Salmon et al. 2011) — the counter-based RNG the device engine also uses      */
 /* ------------------------------------------------------------------------------------------ */
 
 void syo_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < 7; ++r) {
         uint64_t p0 = (uint64_t)0xD2511F53u * c0;
         uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
         uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;

@@ -77,7 +77,7 @@ int32_t syo_step_one(const syo_graph *g, int32_t P, int32_t max_t, int32_t *pos,
 void syo_belief_update(const syo_graph *g, double *belief, const int32_t *hint, int32_t n_hint,
                        int32_t reveal, const int32_t *zero_nodes, int32_t n_zero);
 
-/* counter-based RNG shared with the device path (Philox4x32-10) */
+/* counter-based RNG shared with the device path (Philox4x32-7) */
 void syo_philox4x32(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]);
 
 /* ---- batched env with auto-reset + in-engine uniform-random policy (mirrors the device engine) ---- */

@@ -47,8 +47,8 @@ int sy_env_create(const sy_env_config* c, sy_env** out) {
     if (c->node_stride < c->num_nodes || (c->node_stride & 15))
         return fail(SY_ERR_INVALID, "node_stride must be a multiple of 16 and >= num_nodes%s");
     if (c->num_graphs < 1) return fail(SY_ERR_INVALID, "num_graphs must be >= 1%s");
-    if (c->agent_money < 0 || c->agent_money > 0xffff)
-        return fail(SY_ERR_INVALID, "agent_money must be in [0, 65535]%s");
+    if (c->agent_money < 0 || c->agent_money > 0xfffe)
+        return fail(SY_ERR_INVALID, "agent_money must be in [0, 65534]%s");
     if (c->max_timestep < 0) return fail(SY_ERR_INVALID, "max_timestep must be >= 0%s");
     if (c->reveal_interval < 0) return fail(SY_ERR_INVALID, "reveal_interval must be >= 0%s");
     if (c->waves_per_block < 0 || c->waves_per_block > 16)
@@ -72,7 +72,7 @@ int sy_env_create(const sy_env_config* c, sy_env** out) {
     p.auto_reset = c->auto_reset ? 1 : 0;
     p.env_id_offset = c->env_id_offset;
     p.wave_lds_bytes = (p.NS + 16) * 4 + p.A * p.NS + p.NS * 2;
-    const size_t ell_bytes = (size_t)p.N * SY_ELL_WIDTH * 4;
+    const size_t ell_bytes = (size_t)p.N * SY_ELL_WIDTH * 4 + 2 * SY_LDS_TABLE * sizeof(double);  // board + reward tables
     int wpb = c->waves_per_block ? c->waves_per_block : 8;
     while (wpb > 1 && ell_bytes + (size_t)wpb * p.wave_lds_bytes > kMaxLds) --wpb;
     if (ell_bytes + (size_t)wpb * p.wave_lds_bytes > kMaxLds) {
@@ -180,6 +180,8 @@ int sy_env_rollout(sy_env* env, int32_t T, const sy_rollout_buffers* out, void* 
     sy_rollout_buffers o;
     if (out) o = *out;
     else std::memset(&o, 0, sizeof(o));
+    if (out && (!o.pos || !o.budget || !o.t || !o.action || !o.reward || !o.terminated || !o.truncated || !o.winner))
+        return fail(SY_ERR_INVALID, "sy_env_rollout: only `mask` and `belief` of the record may be NULL%s");
     if (o.mask && (reinterpret_cast<uintptr_t>(o.mask) & 15)) return fail(SY_ERR_INVALID, "rollout mask must be 16-byte aligned%s");
     hipError_t e = sy::launch_engine(env->p, nullptr, T, o, false, env->blocks, env->wpb * 64, env->lds, (hipStream_t)stream);
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_env_rollout launch");

@@ -5,6 +5,8 @@
 
 #include "../../include/sy_env.h"
 
+#define SY_LDS_TABLE 256  // exp(-d) / coverage entries staged in LDS per launch block
+
 namespace sy {
 
 // Passed by value to every engine launch (kernel-argument segment, scalar loads).

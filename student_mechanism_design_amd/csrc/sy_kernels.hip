@@ -22,6 +22,8 @@ namespace sy {
 static constexpr int kWave = 64;
 static constexpr int kD = SY_ELL_WIDTH;  // 16 ELL entries per node
 static constexpr uint32_t kPurposeAct = 1u, kPurposeReset = 2u;
+static constexpr int kPhiloxRounds = 7;
+static constexpr int kLdsTab = SY_LDS_TABLE;  // exp / coverage table entries staged in LDS
 
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wave execute in order; this only stops the compiler from reordering
@@ -32,19 +34,31 @@ __device__ __forceinline__ void wave_lds_fence() {
 }
 
 __device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ int bperm(int byte_addr, int v) { return __builtin_amdgcn_ds_bpermute(byte_addr, v); }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, kWave);
-    return v;
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
 
-// Philox4x32-10 (Salmon et al. 2011), word 0 of the output block.
+// Wave-wide float sum without LDS traffic: DPP butterflies inside each 16-lane row
+// (quad_perm [1,0,3,2], [2,3,0,1], row_ror:4, row_ror:8), then the four row totals via v_readlane.
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x124>(v);
+    v += dpp_mov<0x128>(v);
+    const int iv = __float_as_int(v);
+    return ((__int_as_float(rdlane(iv, 0)) + __int_as_float(rdlane(iv, 16))) + __int_as_float(rdlane(iv, 32))) +
+           __int_as_float(rdlane(iv, 48));
+}
+
+// Philox4x32-7 (Salmon et al. 2011; 7 rounds is the paper's Crush-resistant minimum), word 0.
 __device__ __forceinline__ uint32_t philox_draw(uint64_t gid, uint32_t ctr, uint32_t purpose, uint32_t idx,
                                                 uint32_t k0, uint32_t k1) {
     uint32_t c0 = (uint32_t)gid, c1 = (uint32_t)(gid >> 32), c2 = ctr, c3 = (purpose << 8) | idx;
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < kPhiloxRounds; ++r) {
         uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
         uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
         uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
@@ -57,8 +71,7 @@ __device__ __forceinline__ uint32_t philox_draw(uint64_t gid, uint32_t ctr, uint
 
 // Distinct start nodes, uniform without replacement (replaces np.random.choice(N, A, replace=False),
 // yard.py:112-116).  All values are wave-uniform; lane a returns agent a's start.
-__device__ __forceinline__ int sample_starts(int lane, int A, int N, uint64_t gid, uint32_t ctr, uint32_t k0,
-                                             uint32_t k1) {
+__device__ __noinline__ int sample_starts(int lane, int A, int N, uint64_t gid, uint32_t ctr, uint32_t k0, uint32_t k1) {
     const uint32_t xv = philox_draw(gid, ctr, kPurposeReset, (uint32_t)lane, k0, k1);
     int sorted[SY_MAX_AGENTS];
 #pragma unroll
@@ -87,30 +100,28 @@ __device__ __forceinline__ int sample_starts(int lane, int A, int N, uint64_t gi
 // pass.  Rebuilds the wave's mask rows in LDS and returns, on lane a, agent a's 16-bit "affordable
 // entry" field and the |possible_moves| count the police position reward uses — which the reference
 // evaluates with agent index i instead of i+1, i.e. the budget of the PREVIOUS agent
-// (reward_calculator.py:190; kept for parity).
-__device__ __forceinline__ void scan_masks(const uint32_t* ell_s, uint8_t* mrow, int lane, int A, int N, int NS,
+// (reward_calculator.py:190; kept for parity).  Padding entries carry weight 0xFFFF, above any
+// budget the ABI admits, so "affordable" alone identifies real neighbours.
+__device__ __forceinline__ void scan_masks(const uint32_t* ell_s, uint8_t* mrow, int lane, int A, int NS, int n16,
                                            int pos_v, int mon_v, uint32_t& aff_field, int& quirk_cnt) {
-    const int n16 = (A * NS) >> 4;
     for (int i = lane; i < n16; i += kWave) reinterpret_cast<uint4*>(mrow)[i] = make_uint4(0, 0, 0, 0);
     wave_lds_fence();
     aff_field = 0;
     quirk_cnt = 0;
-    const int d = lane & 15;
+    const int d = lane & 15, grp = lane >> 4, sh = (lane & 3) << 4;
     for (int base = 0; base < A; base += 4) {
-        const int a = base + (lane >> 4);
+        const int a = base + grp;
         const int src = a < A ? a : A - 1;
-        const int pa = __shfl(pos_v, src, kWave);
-        const int ma = __shfl(mon_v, src, kWave);
-        const int mq = __shfl(mon_v, src > 0 ? src - 1 : 0, kWave);
-        const uint32_t ent = ell_s[pa * kD + d];
-        const int nbr = (int)(ent & 0xffffu), w = (int)(ent >> 16);
-        const bool valid = (a < A) && (nbr < N);
-        const bool own = valid && (w <= ma);
-        const bool quirk = valid && (w <= mq);
-        const uint64_t bo = __ballot(own), bq = __ballot(quirk);
-        if (own) mrow[a * NS + nbr] = 1;
-        if (lane >= base && lane < base + 4 && lane < A) {
-            const int sh = (lane & 3) << 4;
+        const int pa = bperm(src << 2, pos_v);
+        int ma = bperm(src << 2, mon_v);
+        const int mq = bperm((src > 0 ? src - 1 : 0) << 2, mon_v);
+        ma = a < A ? ma : -1;
+        const uint32_t ent = ell_s[(pa << 4) | d];
+        const int w = (int)(ent >> 16);
+        const bool own = w <= ma;
+        const uint64_t bo = __ballot(own), bq = __ballot(w <= mq && a < A);
+        if (own) mrow[a * NS + (int)(ent & 0xffffu)] = 1;
+        if ((lane >> 2) == (base >> 2)) {
             aff_field = (uint32_t)(bo >> sh) & 0xffffu;
             quirk_cnt = __popc((uint32_t)(bq >> sh) & 0xffffu);
         }
@@ -120,26 +131,25 @@ __device__ __forceinline__ void scan_masks(const uint32_t* ell_s, uint8_t* mrow,
 
 // Membership test `action in possible_positions` (yard.py:168,218) for caller-given actions:
 // lane a gets ok (affordable neighbour) and the edge cost (yard.py:234-236).
-__device__ __forceinline__ void scan_hits(const uint32_t* ell_s, int lane, int A, int N, int pos_v, int mon_v,
-                                          int act_v, bool& ok, int& cost) {
+__device__ __forceinline__ void scan_hits(const uint32_t* ell_s, int lane, int A, int pos_v, int mon_v, int act_v,
+                                          bool& ok, int& cost) {
     ok = false;
     cost = 0;
-    const int d = lane & 15;
+    const int d = lane & 15, grp = lane >> 4, sh = (lane & 3) << 4;
     for (int base = 0; base < A; base += 4) {
-        const int a = base + (lane >> 4);
+        const int a = base + grp;
         const int src = a < A ? a : A - 1;
-        const int pa = __shfl(pos_v, src, kWave);
-        const int ma = __shfl(mon_v, src, kWave);
-        const int aa = __shfl(act_v, src, kWave);
-        const uint32_t ent = ell_s[pa * kD + d];
+        const int pa = bperm(src << 2, pos_v);
+        const int ma = bperm(src << 2, mon_v);
+        const int aa = bperm(src << 2, act_v);
+        const uint32_t ent = ell_s[(pa << 4) | d];
         const int nbr = (int)(ent & 0xffffu), w = (int)(ent >> 16);
-        const bool hit = (a < A) && (nbr < N) && (w <= ma) && (nbr == aa);
+        const bool hit = (a < A) && (w <= ma) && (nbr == aa);
         const uint64_t bh = __ballot(hit);
-        const int sh = (lane & 3) << 4;
         const uint32_t field = (uint32_t)(bh >> sh) & 0xffffu;
         const int from = sh + (field ? __ffs((int)field) - 1 : 0);
-        const int wsel = __shfl(w, from, kWave);
-        if (lane >= base && lane < base + 4 && lane < A) {
+        const int wsel = bperm(from << 2, w);
+        if ((lane >> 2) == (base >> 2)) {
             ok = field != 0;
             cost = ok ? wsel : 0;
         }
@@ -149,16 +159,12 @@ __device__ __forceinline__ void scan_hits(const uint32_t* ell_s, int lane, int A
 // One diffusion + evidence step of the deterministic belief filter (belief_module.py:69-111 in
 // expectation): b' = normalize((b.P) * lik), P[i][j] = adj/deg(i) (row e_i if isolated),
 // reveal -> delta, zero mass -> uniform.  Belief lives in registers (NR slabs of 64 nodes); the
-// scaled vector c = b/deg goes through the wave's LDS slice for the neighbour gathers.
+// scaled vector c = b/deg goes through the wave's LDS slice for the neighbour gathers.  Each slab
+// gathers only as many ELL columns as its widest node has neighbours (rows are filled left to right).
 template <int NR>
-__device__ __forceinline__ void belief_step(float (&b)[NR], const float (&ideg)[NR], float* c_s,
-                                            const uint32_t* ell_s, int lane, int N, bool reveal, int mrx,
-                                            bool police_ev, int pos_v, int P) {
-    if (reveal) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) b[r] = (lane + 64 * r == mrx) ? 1.0f : 0.0f;
-        return;
-    }
+__device__ __forceinline__ void belief_step(float (&b)[NR], const float (&ideg)[NR], const int (&slab_w)[NR],
+                                            float* c_s, const uint32_t* ell_s, int lane, int N, bool police_ev,
+                                            int pos_v, int P) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int j = lane + 64 * r;
@@ -170,43 +176,50 @@ __device__ __forceinline__ void belief_step(float (&b)[NR], const float (&ideg)[
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int j = lane + 64 * r;
-        float acc = 0.0f;
-        if (j < N) {
-            const uint4* row = reinterpret_cast<const uint4*>(ell_s + j * kD);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint4 v = row[q];
-                acc += c_s[v.x & 0xffffu];
-                acc += c_s[v.y & 0xffffu];
-                acc += c_s[v.z & 0xffffu];
-                acc += c_s[v.w & 0xffffu];
-            }
-            if (ideg[r] == 0.0f) acc += b[r];
-            if (police_ev)
-                for (int k = 1; k <= P; ++k)
-                    if (j == rdlane(pos_v, k)) acc = 0.0f;
+        const int jj = j < N ? j : N - 1;   // tail lanes read a valid row; their result is discarded
+        const uint4* row = reinterpret_cast<const uint4*>(ell_s + (jj << 4));
+        float acc = ideg[r] == 0.0f ? b[r] : 0.0f;
+        const int wq = slab_w[r];           // wave-uniform number of 4-entry chunks in this slab
+        for (int q = 0; q < wq; ++q) {
+            const uint4 v = row[q];
+            acc += c_s[v.x & 0xffffu];
+            acc += c_s[v.y & 0xffffu];
+            acc += c_s[v.z & 0xffffu];
+            acc += c_s[v.w & 0xffffu];
         }
+        if (police_ev)
+            for (int k = 1; k <= P; ++k)
+                if (j == rdlane(pos_v, k)) acc = 0.0f;
+        acc = j < N ? acc : 0.0f;
         b[r] = acc;
         tot += acc;
     }
     tot = wave_sum(tot);
     const float uni = 1.0f / (float)N;
+    const float inv = tot == 0.0f ? 0.0f : 1.0f / tot;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int j = lane + 64 * r;
-        b[r] = j < N ? (tot == 0.0f ? uni : b[r] / tot) : 0.0f;
+        b[r] = j < N ? (tot == 0.0f ? uni : b[r] * inv) : 0.0f;
     }
     wave_lds_fence();
+}
+
+template <typename T>
+__device__ __forceinline__ T* at_bytes(T* base, uint32_t byte_off) {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
 }
 
 // ---------------------------------------------------------------------------------------------
 // The engine kernel: T fused env steps per launch.
 //   EXT = true : actions come from the caller (sy_env_step; T == 1).
 //   EXT = false: uniform-random policy inside the kernel (sy_env_rollout), trajectory recorded.
+// LDS: [board ELL N*64 B][exp table 256 f64][coverage table 256 f64][per wave: belief scratch,
+// mask rows, visit counters].
 // ---------------------------------------------------------------------------------------------
-template <int NR, bool EXT>
+template <int NR, bool EXT, bool REC>
 __global__ __launch_bounds__(1024) void engine_kernel(const EngineParams p, const int32_t* __restrict__ actions,
-                                                      const int T, const sy_rollout_buffers out) {
+                                                      const int T, const sy_rollout_buffers out_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wpb = blockDim.x >> 6;
     const int N = p.N, NS = p.NS, A = p.A, P = p.P, B = p.B;
@@ -214,18 +227,24 @@ __global__ __launch_bounds__(1024) void engine_kernel(const EngineParams p, cons
     const int e = e0 + wid;
 
     uint32_t* ell_s = reinterpret_cast<uint32_t*>(smem);
-    unsigned char* wbase = smem + (size_t)N * kD * 4 + (size_t)wid * p.wave_lds_bytes;
+    double* exp_s = reinterpret_cast<double*>(smem + (size_t)N * kD * 4);
+    double* cov_s = exp_s + kLdsTab;
+    unsigned char* wbase = reinterpret_cast<unsigned char*>(cov_s + kLdsTab) + (size_t)wid * p.wave_lds_bytes;
     float* c_s = reinterpret_cast<float*>(wbase);
     uint8_t* mrow = wbase + (size_t)(NS + 16) * 4;
     uint16_t* vis_s = reinterpret_cast<uint16_t*>(mrow + (size_t)A * NS);
 
-    // ---- stage the block's board (ELL rows) in LDS: coalesced 16-byte loads
+    // ---- stage the block's board (ELL rows) and the reward tables in LDS: coalesced 16-byte loads
     int g = p.env_graph[e0 < B ? e0 : B - 1];
     g = g < 0 ? 0 : (g >= p.G ? p.G - 1 : g);
     {
         const uint4* src = reinterpret_cast<const uint4*>(p.ell + (size_t)g * N * kD);
         uint4* dst = reinterpret_cast<uint4*>(ell_s);
         for (int i = threadIdx.x; i < N * 4; i += blockDim.x) dst[i] = src[i];
+        for (int i = threadIdx.x; i < kLdsTab; i += blockDim.x) {
+            exp_s[i] = i < p.n_exp ? p.exp_tab[i] : 0.0;
+            cov_s[i] = p.cov_tab[i < p.n_cov ? i : p.n_cov - 1];
+        }
     }
     __syncthreads();
     if (e >= B) return;
@@ -233,6 +252,15 @@ __global__ __launch_bounds__(1024) void engine_kernel(const EngineParams p, cons
     const uint16_t* __restrict__ ap = p.apsp + (size_t)g * N * N;
     const uint64_t gid = p.env_id_offset + (uint64_t)e;
     const bool has_belief = p.st.belief != nullptr;
+    const bool is_pol = lane >= 1 && lane <= P;
+    const int n16 = (A * NS) >> 4;
+
+    // per-lane reward coefficients (reward_calculator.py:140-148 for MrX on lane 0, :214-229 for police)
+    const double k0 = lane == 0 ? p.w[4] : p.w[0];
+    const double k1 = lane == 0 ? p.w[5] : p.w[1];
+    const double k2 = lane == 0 ? p.w[6] : p.w[2];
+    const double k3 = 1.0 - (lane == 0 ? p.w[7] : p.w[3]);
+    const double k4 = p.w[9], k5 = p.w[10], k6 = p.w[8];
 
     // ---- load the episode state: coalesced reads of the batched tensors
     int pos_v = lane < A ? p.st.pos[(size_t)e * A + lane] : 0;
@@ -242,15 +270,34 @@ __global__ __launch_bounds__(1024) void engine_kernel(const EngineParams p, cons
     for (int i = lane; i < (NS >> 3); i += kWave)
         reinterpret_cast<uint4*>(vis_s)[i] = reinterpret_cast<const uint4*>(p.st.visits + (size_t)e * NS)[i];
     float b[NR], ideg[NR];
+    int slab_w[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int j = lane + 64 * r;
         b[r] = (has_belief && j < N) ? p.st.belief[(size_t)e * NS + j] : 0.0f;
         ideg[r] = (has_belief && j < N) ? p.inv_deg[(size_t)g * NS + j] : 0.0f;
+        // widest row of the slab, in 4-entry chunks (1/deg -> deg is exact for deg <= 16)
+        const int deg = ideg[r] > 0.0f ? (int)(1.0f / ideg[r] + 0.5f) : 0;
+        int need = (deg + 3) >> 2;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const int other = __shfl_xor(need, o, kWave);
+            need = other > need ? other : need;
+        }
+        slab_w[r] = rdlane(need, 0);
     }
+    int rev_ctr = p.reveal_k > 0 ? p.reveal_k - (t % p.reveal_k) : 0;   // steps until the next reveal
     uint32_t aff = 0;
     int qcnt = 0;
-    if (!EXT) scan_masks(ell_s, mrow, lane, A, N, NS, pos_v, mon_v, aff, qcnt);  // rebuild pre-step masks
+    if (!EXT) scan_masks(ell_s, mrow, lane, A, NS, n16, pos_v, mon_v, aff, qcnt);  // rebuild the pre-step masks
+
+    // ---- trajectory cursors: uniform base pointers advanced once per step + constant 32-bit lane offsets
+    sy_rollout_buffers out = out_arg;
+    const uint32_t off_small = (uint32_t)(e * A + lane) * 4u;
+    const uint32_t off_env = (uint32_t)e;
+    const uint32_t off_mask = (uint32_t)e * (uint32_t)(A * NS) + (uint32_t)lane * 16u;
+    const uint32_t off_bel = ((uint32_t)e * (uint32_t)NS + (uint32_t)lane) * 4u;
+    const size_t BA = (size_t)B * A;
 
     double rew = 0.0;
     int term = 0, trunc = 0, win = 0;
@@ -261,7 +308,7 @@ __global__ __launch_bounds__(1024) void engine_kernel(const EngineParams p, cons
         bool ok_v = false;
         if (EXT) {
             act_v = lane < A ? actions[(size_t)e * A + lane] : -1;
-            scan_hits(ell_s, lane, A, N, pos_v, mon_v, act_v, ok_v, cost_v);
+            scan_hits(ell_s, lane, A, pos_v, mon_v, act_v, ok_v, cost_v);
         } else {
             // uniform over the agent's valid mask, -1 when it is empty (random_agent.py)
             const int k = __popc(aff);
@@ -270,64 +317,73 @@ __global__ __launch_bounds__(1024) void engine_kernel(const EngineParams p, cons
             uint32_t f = aff;
             for (int i = 0; i < r; ++i) f &= f - 1;
             const int bit = f ? __ffs((int)f) - 1 : 0;
-            const uint32_t ent = ell_s[pos_v * kD + bit];
+            const uint32_t ent = ell_s[(pos_v << 4) | bit];
             ok_v = (lane < A) && (k > 0);
             act_v = ok_v ? (int)(ent & 0xffffu) : -1;
             cost_v = ok_v ? (int)(ent >> 16) : 0;
             // ---- B. record the pre-step observation and the action
-            const size_t rec = (size_t)s * B + e;
-            if (lane < A) {
-                if (out.pos) out.pos[rec * A + lane] = pos_v;
-                if (out.budget) out.budget[rec * A + lane] = mon_v;
-                if (out.action) out.action[rec * A + lane] = act_v;
+            if (REC && lane < A) {
+                *at_bytes(out.pos, off_small) = pos_v;
+                *at_bytes(out.budget, off_small) = mon_v;
+                *at_bytes(out.action, off_small) = act_v;
             }
-            if (lane == 0 && out.t) out.t[rec] = t;
-            if (out.mask) {
-                uint4* dst = reinterpret_cast<uint4*>(out.mask + rec * (size_t)A * NS);
-                for (int i = lane; i < ((A * NS) >> 4); i += kWave) dst[i] = reinterpret_cast<const uint4*>(mrow)[i];
+            if (REC && lane == 0) out.t[off_env] = t;
+            if (REC && out.mask) {
+                for (int i = lane; i < n16; i += kWave)
+                    *reinterpret_cast<uint4*>(out.mask + off_mask + (uint32_t)(i - lane) * 16u) =
+                        reinterpret_cast<const uint4*>(mrow)[i];
             }
-            if (out.belief && has_belief) {
+            if (REC && out.belief && has_belief) {
 #pragma unroll
-                for (int r2 = 0; r2 < NR; ++r2) {
-                    const int j = lane + 64 * r2;
-                    if (j < NS) out.belief[rec * NS + j] = b[r2];
-                }
+                for (int r2 = 0; r2 < NR; ++r2)
+                    if (lane + 64 * r2 < NS) *at_bytes(out.belief, off_bel + 256u * r2) = b[r2];
             }
         }
 
         // ---- C. moves.  MrX first against the PRE-move police (yard.py:161-188) ...
+        const int tgt_v = ok_v ? act_v : pos_v;                                   // :168-178, :218-229
+        const uint64_t skipm = __ballot(act_v == -1 || mon_v == 0);               // :210-215
         {
-            const int a0 = rdlane(act_v, 0), p0 = rdlane(pos_v, 0);
-            const int tgt = rdlane((int)ok_v, 0) ? a0 : p0;
-            const bool blocked = __ballot(lane >= 1 && lane <= P && pos_v == tgt) != 0ull;
+            const int tgt = rdlane(tgt_v, 0);
+            const bool blocked = __ballot(is_pol && pos_v == tgt) != 0ull;
             if (!blocked && lane == 0) pos_v = tgt;
         }
         // ... then police strictly in index order, each seeing earlier moves (yard.py:191-243)
-        bool no_money = true;
         for (int k = 1; k <= P; ++k) {
-            const int ak = rdlane(act_v, k), pk = rdlane(pos_v, k), mk = rdlane(mon_v, k);
-            const bool skip = (ak == -1) || (mk == 0);                          // :210-215
-            const int tgt = rdlane((int)ok_v, k) ? ak : pk;                     // :218-229
-            const bool occ = __ballot(lane >= 1 && lane <= P && pos_v == tgt) != 0ull;  // own node included (:231)
-            no_money = no_money && skip;                                        // :216
-            if (!skip && !occ && lane == k) {
+            const int tgt = rdlane(tgt_v, k);
+            const bool occ = __ballot(is_pol && pos_v == tgt) != 0ull;            // own node included (:231)
+            if (!occ && !((skipm >> k) & 1ull) && lane == k) {
                 pos_v = tgt;
-                mon_v -= cost_v;                                                // :234-236
+                mon_v -= cost_v;                                                  // :234-236
             }
         }
+        const uint64_t polm = ((1ull << P) - 1ull) << 1;
+        const bool no_money = (skipm & polm) == polm;                             // :191,216
         // node_visit_counts (yard.py:244-245): police never share a node, so no conflicts
         int vc = 0;
-        if (lane >= 1 && lane <= P) {
+        if (is_pol) {
             vc = (int)vis_s[pos_v] + 1;
             vis_s[pos_v] = (uint16_t)vc;
         }
+        const int mrx = rdlane(pos_v, 0);
+        // shortest-path lookups for the shaped rewards are issued now and consumed after the scan
+        const int row = pos_v * N;
+        int dm = 0x7fffffff;
+        int dj[SY_MAX_AGENTS - 1];
+#pragma unroll
+        for (int j = 1; j < SY_MAX_AGENTS; ++j) dj[j - 1] = 0;
+        if (is_pol) {
+            dm = (int)ap[row + mrx];
+#pragma unroll
+            for (int j = 1; j < SY_MAX_AGENTS; ++j)
+                if (j <= P) dj[j - 1] = (int)ap[row + rdlane(pos_v, j)];
+        }
 
         // ---- F. post-move scan: masks for the next observation + position-reward counts
-        scan_masks(ell_s, mrow, lane, A, N, NS, pos_v, mon_v, aff, qcnt);
+        scan_masks(ell_s, mrow, lane, A, NS, n16, pos_v, mon_v, aff, qcnt);
 
         // ---- D. outcome priority (reward_calculator.py:63-90), flags shared by all agents
-        const int mrx = rdlane(pos_v, 0);
-        const bool captured = __ballot(lane >= 1 && lane <= P && pos_v == mrx) != 0ull;
+        const bool captured = __ballot(is_pol && pos_v == mrx) != 0ull;
         const bool timeout = t > p.max_t;  // pre-increment timestep
         term = (captured || (!timeout && no_money)) ? 1 : 0;
         trunc = (!captured && timeout) ? 1 : 0;
@@ -337,9 +393,6 @@ __global__ __launch_bounds__(1024) void engine_kernel(const EngineParams p, cons
             rew = captured ? (lane == 0 ? -1.0 : 1.0) : (lane == 0 ? 1.0 : 0.0);
         } else {
             // shaped rewards (reward_calculator.py:94-266) in float64, reference operation order
-            const bool is_pol = lane >= 1 && lane <= P;
-            const int row = pos_v * N;
-            const int dm = is_pol ? (int)ap[row + mrx] : 0x7fffffff;
             int mn = 0x7fffffff, sum = 0;
             for (int k = 1; k <= P; ++k) {
                 const int dk = rdlane(dm, k);
@@ -347,40 +400,48 @@ __global__ __launch_bounds__(1024) void engine_kernel(const EngineParams p, cons
                 sum += dk;
             }
             const double ts = (double)t;
+            const double cntd = (double)qcnt;
             if (lane == 0) {
                 const double closest = (double)mn, avg = (double)sum / (double)P;
-                rew = ((p.w[4] * (-1.0 / (closest + 1.0)) + p.w[5] * (-1.0 / (avg + 1.0))) + p.w[6] * (double)qcnt) +
-                      (1.0 - p.w[7]) * (0.1 * ts);
-            } else {
+                rew = ((k0 * (-1.0 / (closest + 1.0)) + k1 * (-1.0 / (avg + 1.0))) + k2 * cntd) + k3 * (0.1 * ts);
+            } else if (is_pol) {
                 double group = 0.0, overlap = 0.0, prox = 0.0;
-                for (int j = 1; j <= P; ++j) {
-                    const int pj = rdlane(pos_v, j);
-                    if (is_pol && j != lane) {
-                        const int dij = (int)ap[row + pj];
-                        const double ex = dij < p.n_exp ? p.exp_tab[dij] : 0.0;
+#pragma unroll
+                for (int j = 1; j < SY_MAX_AGENTS; ++j) {
+                    if (j <= P && j != lane) {
+                        const int dij = dj[j - 1];
+                        double ex;
+                        if (EXT) ex = dij < p.n_exp ? p.exp_tab[dij] : 0.0;
+                        else ex = dij < kLdsTab ? exp_s[dij] : (dij < p.n_exp ? p.exp_tab[dij] : 0.0);
                         group += ex;
                         if (dij <= 1) overlap += 1.0;
                         else prox += ex;
                     }
                 }
-                if (is_pol) {
-                    const double e_mrx = dm < p.n_exp ? p.exp_tab[dm] : 0.0;
-                    const double cov = p.cov_tab[vc < p.n_cov ? vc : p.n_cov - 1];
-                    rew = (((((p.w[0] * e_mrx + p.w[1] * group) + p.w[2] * (double)qcnt) + (1.0 - p.w[3]) * (0.05 * ts)) +
-                            p.w[9] * prox) - p.w[10] * overlap) + p.w[8] * cov;
+                double e_mrx, cov;
+                if (EXT) {
+                    e_mrx = dm < p.n_exp ? p.exp_tab[dm] : 0.0;
+                    cov = p.cov_tab[vc < p.n_cov ? vc : p.n_cov - 1];
+                } else {
+                    e_mrx = dm < kLdsTab ? exp_s[dm] : (dm < p.n_exp ? p.exp_tab[dm] : 0.0);
+                    cov = vc < kLdsTab ? cov_s[vc] : p.cov_tab[vc < p.n_cov ? vc : p.n_cov - 1];
                 }
+                rew = (((((k0 * e_mrx + k1 * group) + k2 * cntd) + k3 * (0.05 * ts)) + k4 * prox) - k5 * overlap) + k6 * cov;
             }
         }
         t += 1;   // yard.py:355
         sc += 1;
-        if (!EXT) {
-            const size_t rec = (size_t)s * B + e;
-            if (lane < A && out.reward) out.reward[rec * A + lane] = rew;
+        if (REC) {
+            if (lane < A) *at_bytes(out.reward, off_small * 2u) = rew;
             if (lane == 0) {
-                if (out.terminated) out.terminated[rec] = (uint8_t)term;
-                if (out.truncated) out.truncated[rec] = (uint8_t)trunc;
-                if (out.winner) out.winner[rec] = (int8_t)win;
+                out.terminated[off_env] = (uint8_t)term;
+                out.truncated[off_env] = (uint8_t)trunc;
+                out.winner[off_env] = (int8_t)win;
             }
+            out.pos += BA; out.budget += BA; out.action += BA; out.reward += BA;
+            out.t += B; out.terminated += B; out.truncated += B; out.winner += B;
+            if (out.mask) out.mask += BA * NS;
+            if (out.belief) out.belief += (size_t)B * NS;
         }
 
         // ---- E. next episode (auto-reset) or belief update for the new positions
@@ -389,6 +450,7 @@ __global__ __launch_bounds__(1024) void engine_kernel(const EngineParams p, cons
             pos_v = lane < A ? st : 0;
             mon_v = lane == 0 ? SY_MRX_MONEY : (lane < A ? p.money0 : 0);   // yard.py:117-119
             t = 0;
+            rev_ctr = p.reveal_k;
             for (int i = lane; i < (NS >> 3); i += kWave) reinterpret_cast<uint4*>(vis_s)[i] = make_uint4(0, 0, 0, 0);
             if (has_belief) {
                 const int m0 = rdlane(pos_v, 0);
@@ -400,10 +462,21 @@ __global__ __launch_bounds__(1024) void engine_kernel(const EngineParams p, cons
                 }
             }
             wave_lds_fence();
-            scan_masks(ell_s, mrow, lane, A, N, NS, pos_v, mon_v, aff, qcnt);
-        } else if (has_belief) {
-            const bool reveal = p.reveal_k > 0 && (t % p.reveal_k) == 0;
-            belief_step<NR>(b, ideg, c_s, ell_s, lane, N, reveal, mrx, p.police_ev != 0, pos_v, P);
+            scan_masks(ell_s, mrow, lane, A, NS, n16, pos_v, mon_v, aff, qcnt);
+        } else {
+            bool reveal = false;
+            if (p.reveal_k > 0 && --rev_ctr == 0) {   // post-increment timestep is a multiple of reveal_k
+                reveal = true;
+                rev_ctr = p.reveal_k;
+            }
+            if (has_belief) {
+                if (reveal) {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) b[r] = (lane + 64 * r == mrx) ? 1.0f : 0.0f;
+                } else {
+                    belief_step<NR>(b, ideg, slab_w, c_s, ell_s, lane, N, p.police_ev != 0, pos_v, P);
+                }
+            }
         }
     }
 
@@ -424,7 +497,7 @@ __global__ __launch_bounds__(1024) void engine_kernel(const EngineParams p, cons
         reinterpret_cast<uint4*>(p.st.visits + (size_t)e * NS)[i] = reinterpret_cast<const uint4*>(vis_s)[i];
     {
         uint4* dst = reinterpret_cast<uint4*>(p.st.mask + (size_t)e * A * NS);
-        for (int i = lane; i < ((A * NS) >> 4); i += kWave) dst[i] = reinterpret_cast<const uint4*>(mrow)[i];
+        for (int i = lane; i < n16; i += kWave) dst[i] = reinterpret_cast<const uint4*>(mrow)[i];
     }
     if (has_belief) {
 #pragma unroll
@@ -447,7 +520,7 @@ __global__ __launch_bounds__(1024) void reset_kernel(const EngineParams p, const
     const int e0 = blockIdx.x * wpb;
     const int e = e0 + wid;
     uint32_t* ell_s = reinterpret_cast<uint32_t*>(smem);
-    unsigned char* wbase = smem + (size_t)N * kD * 4 + (size_t)wid * p.wave_lds_bytes;
+    unsigned char* wbase = smem + (size_t)N * kD * 4 + 2 * kLdsTab * sizeof(double) + (size_t)wid * p.wave_lds_bytes;
     uint8_t* mrow = wbase + (size_t)(NS + 16) * 4;
     int g = p.env_graph[e0 < B ? e0 : B - 1];
     g = g < 0 ? 0 : (g >= p.G ? p.G - 1 : g);
@@ -471,7 +544,7 @@ __global__ __launch_bounds__(1024) void reset_kernel(const EngineParams p, const
     const int mon_v = lane == 0 ? SY_MRX_MONEY : (lane < A ? p.money0 : 0);
     uint32_t aff;
     int qcnt;
-    scan_masks(ell_s, mrow, lane, A, N, NS, pos_v, mon_v, aff, qcnt);
+    scan_masks(ell_s, mrow, lane, A, NS, (A * NS) >> 4, pos_v, mon_v, aff, qcnt);
     if (lane < A) {
         p.st.pos[(size_t)e * A + lane] = pos_v;
         p.st.budget[(size_t)e * A + lane] = mon_v;
@@ -549,8 +622,9 @@ __global__ __launch_bounds__(256) void belief_update_kernel(const uint32_t* __re
         ideg[r] = j < N ? inv_deg[j] : 0.0f;
     }
     const int rv = reveal ? reveal[q] : -1;
-    if (rv >= 0) {
-        belief_step<NR>(b, ideg, c_s, ell_s, lane, N, true, rv, false, 0, 0);
+    if (rv >= 0) {   // :86-88 every particle on the revealed node
+#pragma unroll
+        for (int r = 0; r < NR; ++r) b[r] = (lane + 64 * r == rv) ? 1.0f : 0.0f;
     } else {
         // diffusion without normalisation, then the hint likelihood, then normalise
 #pragma unroll
@@ -610,9 +684,11 @@ template <int NR>
 static hipError_t launch_engine_nr(const EngineParams& p, const int32_t* actions, int T, const sy_rollout_buffers& out,
                                    bool ext, int blocks, int threads, size_t lds, hipStream_t stream) {
     if (ext) {
-        hipLaunchKernelGGL((engine_kernel<NR, true>), dim3(blocks), dim3(threads), lds, stream, p, actions, T, out);
+        hipLaunchKernelGGL((engine_kernel<NR, true, false>), dim3(blocks), dim3(threads), lds, stream, p, actions, T, out);
+    } else if (out.pos) {
+        hipLaunchKernelGGL((engine_kernel<NR, false, true>), dim3(blocks), dim3(threads), lds, stream, p, actions, T, out);
     } else {
-        hipLaunchKernelGGL((engine_kernel<NR, false>), dim3(blocks), dim3(threads), lds, stream, p, actions, T, out);
+        hipLaunchKernelGGL((engine_kernel<NR, false, false>), dim3(blocks), dim3(threads), lds, stream, p, actions, T, out);
     }
     return hipGetLastError();
 }

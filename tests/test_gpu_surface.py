@@ -1,0 +1,140 @@
+"""GPU tests of the reference-shaped surfaces: the B=1 PettingZoo-style facade (golden replay through
+`reset/step/get_possible_moves`) and the policy-driven collector."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from tests.helpers import NONE_ACTION, load_trace, trace_index  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+FACADE_TRACES = ["trace_s0_n15_p2_m10_noop_ep0.npz", "trace_s2_n15_p2_m10_mixed_ep1.npz",
+                 "trace_s5_n20_p4_m20_chase_ep0.npz", "trace_s7_n25_p6_m8_swarm_ep1.npz",
+                 "trace_s15_n24_p4_m12_mixed_live_ep2.npz", "trace_s10_n200_p4_m20_random_valid_ep0.npz"]
+
+
+@pytest.fixture(scope="module")
+def sy():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import student_mechanism_design_amd as sy_mod
+    sy_mod._lib.load()
+    return sy_mod
+
+
+WEIGHT_NAMES = ["Police_distance", "Police_group", "Police_position", "Police_time", "Mrx_closest", "Mrx_average",
+                "Mrx_position", "Mrx_time", "Police_coverage", "Police_proximity", "Police_overlap_penalty"]
+
+
+@pytest.mark.parametrize("name", FACADE_TRACES)
+def test_facade_replays_golden_trace(sy, name):
+    """Drive the reference's own call pattern (dict actions incl. None / -1) through the facade."""
+    from student_mechanism_design_amd.pettingzoo_api import CustomEnvironment, as_tensordict
+    assert name in [e["file"] for e in trace_index()]
+    tr = load_trace(name)
+    N, P = int(tr["N"]), int(tr["P"])
+    weights = {k: float(v) for k, v in zip(WEIGHT_NAMES, tr["weights"])}
+    env = CustomEnvironment(number_of_agents=P, agent_money=int(tr["money0"]), reward_weights=weights, logger=None,
+                            epoch=0, graph_nodes=N, graph_edges=int(tr["edge_links"].shape[0]),
+                            vis_configs={"visualize_game": False})
+    board = sy.make_board(N, tr["edge_links"], tr["edge_w"])
+    obs, infos = env.reset(episode=0, options={"board": board, "starts": tr["starts"]})
+    assert env.possible_agents == ["MrX"] + [f"Police{k}" for k in range(P)] and env.agents == env.possible_agents
+    assert set(obs["MrX"].keys()) >= {"adjacency_matrix", "node_features", "edge_index", "edge_features", "MrX_pos",
+                                      "Polices_pos", "Currency", "action_mask", "agent_position", "agent_budget"}
+    for i, a in enumerate(env.possible_agents):
+        np.testing.assert_array_equal(obs[a]["action_mask"], tr["mask0"][i])
+        np.testing.assert_array_equal(env.get_possible_moves(i), np.nonzero(tr["mask0"][i])[0])
+    assert env.action_space("MrX").n == N
+    for s in range(tr["actions"].shape[0]):
+        acts = {a: (None if tr["actions"][s][i] == NONE_ACTION else int(tr["actions"][s][i]))
+                for i, a in enumerate(env.possible_agents)}
+        obs, rew, term, trunc, infos = env.step(acts)
+        assert [env.MrX_pos[0]] + env.police_positions == list(tr["pos"][s])
+        assert env.agents_money == list(tr["money"][s])
+        assert env.timestep == int(tr["t_after"][s])
+        assert all(v == bool(tr["terminated"][s]) for v in term.values())
+        assert all(v == bool(tr["truncated"][s]) for v in trunc.values())
+        assert {None: 0, "Police": 1, "MrX": 2}[env.current_winner] == int(tr["winner"][s])
+        np.testing.assert_allclose([rew[a] for a in env.possible_agents], tr["reward"][s], rtol=1e-12, atol=1e-12)
+        for i, a in enumerate(env.possible_agents):
+            np.testing.assert_array_equal(obs[a]["action_mask"], tr["masks"][s][i])
+            assert obs[a]["MrX_pos"] == tr["pos"][s][0] and obs[a]["Polices_pos"] == list(tr["pos"][s][1:])
+            assert obs[a]["Currency"] == list(tr["money"][s][1:])
+        assert obs["MrX"]["node_features"].sum() == P + 1
+        vis = np.zeros(N, np.int32)
+        for k, c in env.node_visit_counts.items():
+            vis[k] = c
+        np.testing.assert_array_equal(vis, tr["visits"][s])
+    if tr["terminated"][-1] or tr["truncated"][-1]:
+        assert env.agents == []          # yard.py:260-266
+    td = as_tensordict(env, obs, rew, term, trunc)
+    assert td["MrX"]["observation"]["MrX_pos"].shape == (1, N)
+    assert td["Police0"]["observation"]["Polices_pos"].shape == (1, P, N)
+    assert td["Police0"]["observation"]["Polices_pos"].sum(dim=1).shape == (1, N)   # mappo_trainer.py:197
+    assert env.get_distance(0, 0) == 0.0
+    env.close()
+
+
+def test_facade_samples_boards_like_the_reference(sy):
+    from student_mechanism_design_amd.pettingzoo_api import CustomEnvironment
+    w = {k: 0.5 for k in WEIGHT_NAMES}
+    env = CustomEnvironment(2, 10, w, None, 0, 15, 20, None, seed=3)
+    e0 = env.board.edge_links.copy()
+    env.reset(episode=1)
+    assert env.board.num_edges == env.actual_num_edges == 20
+    assert not np.array_equal(e0, env.board.edge_links)       # new board per episode (yard.py:90-95)
+    pos = [env.MrX_pos[0]] + env.police_positions
+    assert len(set(pos)) == 3 and env.agents_money == [1000, 10, 10] and env.timestep == 0
+    # reference test/env_test.py: all agents play -1 -> no-money termination, MrX wins
+    obs, rew, term, trunc, _ = env.step({a: -1 for a in env.possible_agents})
+    assert all(term.values()) and not any(trunc.values()) and env.current_winner == "MrX"
+    assert rew == {"MrX": 1.0, "Police0": 0.0, "Police1": 0.0}
+    env.close()
+
+
+def test_policy_driven_collector_matches_fused_rollout(sy):
+    """A torch policy that reproduces the engine's random choice must collect the same trajectory as
+    the fused kernel; also exercises masked sampling + returns on device tensors."""
+    from student_mechanism_design_amd import collector as col
+    boards = sy.sample_board_pool(2, 40, 70, seed=4)
+    w = np.linspace(0.1, 0.9, 11)
+    a = sy.BatchedScotlandYardEnv(96, boards, 3, 9, w, seed=8, reveal_interval=5)
+    b = sy.BatchedScotlandYardEnv(96, boards, 3, 9, w, seed=8, reveal_interval=5)
+    fused = col.RolloutCollector(a, None, frames_per_batch=40).collect()
+    script = fused["action"]
+    step = {"i": 0}
+
+    def replay_policy(obs):
+        s = step["i"]
+        step["i"] += 1
+        return script[s], torch.zeros_like(script[s], dtype=torch.float32), torch.zeros(96, device=script.device)
+
+    got = col.RolloutCollector(b, replay_policy, frames_per_batch=40).collect()
+    for k in ("pos", "budget", "t", "action", "mask", "belief", "reward", "terminated", "truncated", "winner"):
+        assert torch.equal(got[k], fused[k]), k
+    assert got["log_prob"].shape == (40, 96, 4) and got["value"].shape == (40, 96)
+
+    # a masked-softmax policy only ever emits legal moves
+    c = sy.BatchedScotlandYardEnv(64, boards, 3, 9, w, seed=9)
+    gen = torch.Generator(device=c.device).manual_seed(0)
+
+    def softmax_policy(obs):
+        mask = obs["action_mask"]
+        logits = torch.randn(mask.shape, device=mask.device, generator=gen)
+        act, logp, _ = col.masked_categorical_sample(torch.softmax(logits, -1), mask, generator=gen)
+        empty = mask.sum(-1) == 0
+        act = torch.where(empty, torch.full_like(act, -1), act)
+        return act.to(torch.int32), logp.float(), None
+
+    rec = col.RolloutCollector(c, softmax_policy, frames_per_batch=25).collect()
+    act, mask = rec["action"].long(), rec["mask"][..., : c.N].bool()
+    legal = torch.gather(mask, -1, act.clamp_min(0).unsqueeze(-1)).squeeze(-1)
+    assert bool((legal | (act < 0)).all())
+    done = (rec["terminated"] | rec["truncated"]).bool()
+    ret = col.discounted_returns(rec["reward"], done, 0.99)
+    adv, ret2 = col.gae(rec["reward"], torch.zeros_like(rec["reward"]), done, torch.zeros_like(rec["reward"][0]), 0.99, 1.0)
+    torch.testing.assert_close(ret, ret2)
+    for e in (a, b, c):
+        e.close()

@@ -67,7 +67,7 @@ typedef struct sy_env_config {
     int32_t police_evidence;   /* 1: belief is zeroed on police-occupied nodes                */
     int32_t belief_init_onehot;/* 1: belief starts as a delta on MrX's start (else uniform)   */
     int32_t auto_reset;        /* 1: a finished episode restarts inside step/rollout          */
-    int32_t waves_per_block;   /* envs per launch block (1..16); 0 = engine default           */
+    int32_t waves_per_block;   /* envs per launch block (1..8); 0 = engine default            */
     uint64_t env_id_offset;    /* global index of env 0 (rank * B): distinct RNG sub-streams  */
 } sy_env_config;
 
@@ -86,20 +86,22 @@ typedef struct sy_env_state {
     int8_t *winner;
 } sy_env_state;
 
-/* rollout record, leading dims [T][B] (all device); `mask` and `belief` may be NULL to skip them.
- * Row s holds the observation BEFORE step s, the action taken, and that step's outcome. */
+/* Rollout record (all device).  `record` is one packed row of RW = sy_record_words(A) int32 words per
+ * env and step, [T][B][RW], written as a single coalesced store:
+ *   words [0, 2A)   reward, A float64 values          (this step's outcome)
+ *   words [2A, 3A)  pos     (observation BEFORE the step)
+ *   words [3A, 4A)  budget  (before the step)
+ *   words [4A, 5A)  action taken (-1 = none)
+ *   word  5A        t (before the step);  5A+1 terminated;  5A+2 truncated;  5A+3 winner
+ * `mask` [T][B][A][NS] and `belief` [T][B][NS] hold the observation before the step; either may be NULL. */
 typedef struct sy_rollout_buffers {
-    int32_t *pos;        /* [T][B][A]     */
-    int32_t *budget;     /* [T][B][A]     */
-    int32_t *t;          /* [T][B]        */
-    int32_t *action;     /* [T][B][A]     */
-    uint8_t *mask;       /* [T][B][A][NS] */
-    float *belief;       /* [T][B][NS]    */
-    double *reward;      /* [T][B][A]     */
-    uint8_t *terminated; /* [T][B]        */
-    uint8_t *truncated;  /* [T][B]        */
-    int8_t *winner;      /* [T][B]        */
+    int32_t *record;
+    uint8_t *mask;
+    float *belief;
 } sy_rollout_buffers;
+
+/* dwords per record row for A = num_police + 1 agents: 5A+4 rounded up to a multiple of 4 */
+int sy_record_words(int32_t num_agents);
 
 int sy_abi_version(void);
 const char *sy_last_error(void);
@@ -113,7 +115,7 @@ int sy_env_launch_info(const sy_env *env, int32_t *waves_per_block, int32_t *blo
 /* board + shortest-path tables (replaces board.edge_links/edges yard.py:91-93 and Pathfinder.set_board
  * pathfinding.py:25-32); all device pointers */
 int sy_env_set_graph_pool(sy_env *env, const uint32_t *ell, const uint16_t *apsp, const float *inv_deg,
-                          const int32_t *env_graph);
+                          const int32_t *env_graph, int32_t max_degree /* widest ELL row of the pool; 0 = unknown */);
 /* the 11 reward weights (host array, order = REWARD_WEIGHT_NAMES reward_net.py:5-17) and the device
  * tables exp_tab[d] = exp(-d), cov_tab[v] = exp(-log1p(v)) (reward_calculator.py:184-207) */
 int sy_env_set_rewards(sy_env *env, const double *weights_host, const double *exp_tab, int32_t n_exp,

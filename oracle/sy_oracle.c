@@ -312,6 +312,14 @@ static inline uint32_t draw(uint64_t gid, uint32_t ctr, uint32_t purpose, uint32
     return o[0];
 }
 
+/* action draws: one Philox block serves 4 consecutive steps (word = step_count & 3) */
+static inline uint32_t draw_action(uint64_t gid, uint32_t step_count, uint32_t agent, uint64_t seed) {
+    uint32_t o[4];
+    syo_philox4x32((uint32_t)gid, (uint32_t)(gid >> 32), step_count >> 2, (PURPOSE_ACT << 8) | agent,
+                   (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    return o[step_count & 3u];
+}
+
 static inline uint32_t mulhi32(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -426,7 +434,7 @@ static void sample_actions(const syo_batch_config *c, const syo_graph *g, const 
     int32_t nodes[4096];
     for (int32_t a = 0; a < A; ++a) {
         int32_t k = syo_possible_moves(g, s->pos[(size_t)e * A + a], s->money[(size_t)e * A + a], nodes, NULL);
-        uint32_t x = draw(c->env_id_offset + (uint64_t)e, s->step_count[e], PURPOSE_ACT, (uint32_t)a, seed);
+        uint32_t x = draw_action(c->env_id_offset + (uint64_t)e, s->step_count[e], (uint32_t)a, seed);
         act[a] = k == 0 ? -1 : nodes[mulhi32(x, (uint32_t)k)];
     }
 }

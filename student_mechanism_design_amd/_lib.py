@@ -32,11 +32,10 @@ class EnvState(C.Structure):
 
 
 class RolloutBuffers(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("pos", "budget", "t", "action", "mask", "belief", "reward",
-                                          "terminated", "truncated", "winner")]
+    _fields_ = [(n, C.c_void_p) for n in ("record", "mask", "belief")]
 
 
-EXPORTS = ["sy_abi_version", "sy_last_error", "sy_env_create", "sy_env_destroy", "sy_env_launch_info",
+EXPORTS = ["sy_abi_version", "sy_record_words", "sy_last_error", "sy_env_create", "sy_env_destroy", "sy_env_launch_info",
            "sy_env_set_graph_pool", "sy_env_set_rewards", "sy_env_bind_state", "sy_env_reset", "sy_env_reset_to",
            "sy_env_step", "sy_env_rollout", "sy_action_mask_dense", "sy_belief_update"]
 
@@ -56,10 +55,11 @@ def load():
     vp, i32, u64 = C.c_void_p, C.c_int32, C.c_uint64
     lib.sy_abi_version.restype = C.c_int
     lib.sy_last_error.restype = C.c_char_p
+    lib.sy_record_words.argtypes = [i32]
     lib.sy_env_create.argtypes = [C.POINTER(EnvConfig), C.POINTER(vp)]
     lib.sy_env_destroy.argtypes = [vp]
     lib.sy_env_launch_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
-    lib.sy_env_set_graph_pool.argtypes = [vp, vp, vp, vp, vp]
+    lib.sy_env_set_graph_pool.argtypes = [vp, vp, vp, vp, vp, i32]
     lib.sy_env_set_rewards.argtypes = [vp, C.POINTER(C.c_double), vp, i32, vp, i32]
     lib.sy_env_bind_state.argtypes = [vp, C.POINTER(EnvState)]
     lib.sy_env_reset.argtypes = [vp, vp, u64, vp]

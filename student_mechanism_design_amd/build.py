@@ -34,7 +34,8 @@ def build_extension(force=False, verbose=False):
     if not force and not is_stale():
         return LIB
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-           "-Wall", "-Wno-unused-function"] + [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
+           "-Wall", "-Wno-unused-function"] + os.environ.get("SY_HIPCC_FLAGS", "").split() + \
+        [os.path.join(CSRC, s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -80,7 +80,7 @@ def gae(rewards, values, dones, last_value, gamma: float, lam: float):
 def pack_record(record: Dict[str, Optional[torch.Tensor]]):
     """Flatten a rollout record {name: [T, B, ...]} into one uint8 buffer [B_total_bytes] per env-major
     layout, plus the metadata needed to unpack it."""
-    names = sorted(k for k, v in record.items() if v is not None)
+    names = sorted(k for k, v in record.items() if v is not None and k != "record")  # `record` aliases the named views
     parts, meta = [], []
     for k in names:
         v = record[k].contiguous()
@@ -105,7 +105,7 @@ def unpack_record(buf: torch.Tensor, meta, world: int):
 def gather_trajectories(record: Dict[str, Optional[torch.Tensor]], group=None):
     """All ranks end up with the whole job's trajectories [T, world*B, ...]: ONE collective."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return {k: v for k, v in record.items() if v is not None}
+        return {k: v for k, v in record.items() if v is not None and k != "record"}
     world = dist.get_world_size(group)
     buf, meta = pack_record(record)
     out = torch.empty(world * buf.numel(), dtype=torch.uint8, device=buf.device)

@@ -34,6 +34,7 @@ constexpr size_t kMaxLds = 160 * 1024;
 extern "C" {
 
 int sy_abi_version(void) { return SY_ABI_VERSION; }
+int sy_record_words(int32_t num_agents) { return (5 * num_agents + 4 + 3) & ~3; }
 const char* sy_last_error(void) { return g_err; }
 
 int sy_env_create(const sy_env_config* c, sy_env** out) {
@@ -51,8 +52,8 @@ int sy_env_create(const sy_env_config* c, sy_env** out) {
         return fail(SY_ERR_INVALID, "agent_money must be in [0, 65534]%s");
     if (c->max_timestep < 0) return fail(SY_ERR_INVALID, "max_timestep must be >= 0%s");
     if (c->reveal_interval < 0) return fail(SY_ERR_INVALID, "reveal_interval must be >= 0%s");
-    if (c->waves_per_block < 0 || c->waves_per_block > 16)
-        return fail(SY_ERR_INVALID, "waves_per_block must be in [0, 16]%s");
+    if (c->waves_per_block < 0 || c->waves_per_block > 8)
+        return fail(SY_ERR_INVALID, "waves_per_block must be in [0, 8]%s");
     sy_env* e = new (std::nothrow) sy_env();
     if (!e) return fail(SY_ERR_INVALID, "out of host memory%s");
     std::memset(e, 0, sizeof(*e));
@@ -71,9 +72,15 @@ int sy_env_create(const sy_env_config* c, sy_env** out) {
     p.belief_onehot = c->belief_init_onehot ? 1 : 0;
     p.auto_reset = c->auto_reset ? 1 : 0;
     p.env_id_offset = c->env_id_offset;
-    p.wave_lds_bytes = (p.NS + 16) * 4 + p.A * p.NS + p.NS * 2;
-    const size_t ell_bytes = (size_t)p.N * SY_ELL_WIDTH * 4 + 2 * SY_LDS_TABLE * sizeof(double);  // board + reward tables
+    // per-episode LDS slice: mask rows, visit counters, belief scratch, hand-off ring, sync words
+    p.wave_lds_bytes = p.A * p.NS + p.NS * 2 + (p.NS + 16) * 4 + SY_RING * 32 + 16 + 256;
+    p.rec_words = sy_record_words(p.A);
+    p.scan_w = 16;
+    // per-block LDS: board ELL (64 B/node) + belief gather offsets (32 B/node) + reward tables
+    const size_t ell_bytes = (size_t)p.N * SY_ELL_WIDTH * 6 + (size_t)(3 * SY_LDS_TABLE + 2 + SY_LDS_AVGTAB + 16) * sizeof(double);
+    // with a belief every episode runs two waves (move + belief), so a 1024-thread block holds 8 episodes
     int wpb = c->waves_per_block ? c->waves_per_block : 8;
+    if (wpb > 8) wpb = 8;
     while (wpb > 1 && ell_bytes + (size_t)wpb * p.wave_lds_bytes > kMaxLds) --wpb;
     if (ell_bytes + (size_t)wpb * p.wave_lds_bytes > kMaxLds) {
         delete e;
@@ -100,13 +107,15 @@ int sy_env_launch_info(const sy_env* env, int32_t* wpb, int32_t* blocks, int32_t
 }
 
 int sy_env_set_graph_pool(sy_env* env, const uint32_t* ell, const uint16_t* apsp, const float* inv_deg,
-                          const int32_t* env_graph) {
+                          const int32_t* env_graph, int32_t max_degree) {
     if (!env || !ell || !apsp || !inv_deg || !env_graph) return fail(SY_ERR_INVALID, "sy_env_set_graph_pool: null argument%s");
     if ((reinterpret_cast<uintptr_t>(ell) & 15)) return fail(SY_ERR_INVALID, "ell must be 16-byte aligned%s");
     env->p.ell = ell;
     env->p.apsp = apsp;
     env->p.inv_deg = inv_deg;
     env->p.env_graph = env_graph;
+    if (max_degree < 0 || max_degree > SY_ELL_WIDTH) return fail(SY_ERR_INVALID, "max_degree must be in [0, 16] (0 = unknown)%s");
+    env->p.scan_w = max_degree == 0 ? 16 : (max_degree <= 8 ? 8 : (max_degree <= 12 ? 12 : 16));
     env->has_graph = true;
     return SY_OK;
 }
@@ -148,7 +157,7 @@ int sy_env_reset(sy_env* env, const uint8_t* env_sel, uint64_t seed, void* strea
     if (rc) return rc;
     env->p.seed_lo = (uint32_t)seed;
     env->p.seed_hi = (uint32_t)(seed >> 32);
-    hipError_t e = sy::launch_reset(env->p, env_sel, nullptr, env_sel ? 0 : 1, env->blocks, env->wpb * 64, env->lds,
+    hipError_t e = sy::launch_reset(env->p, env_sel, nullptr, env_sel ? 0 : 1, env->blocks, env->wpb, env->lds,
                                     (hipStream_t)stream);
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_env_reset launch");
 }
@@ -157,7 +166,7 @@ int sy_env_reset_to(sy_env* env, const int32_t* starts, void* stream) {
     int rc = ready(env, "sy_env_reset_to");
     if (rc) return rc;
     if (!starts) return fail(SY_ERR_INVALID, "sy_env_reset_to: null starts%s");
-    hipError_t e = sy::launch_reset(env->p, nullptr, starts, 1, env->blocks, env->wpb * 64, env->lds, (hipStream_t)stream);
+    hipError_t e = sy::launch_reset(env->p, nullptr, starts, 1, env->blocks, env->wpb, env->lds, (hipStream_t)stream);
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_env_reset_to launch");
 }
 
@@ -168,7 +177,7 @@ int sy_env_step(sy_env* env, const int32_t* actions, void* stream) {
     if (!actions) return fail(SY_ERR_INVALID, "sy_env_step: null actions%s");
     sy_rollout_buffers none;
     std::memset(&none, 0, sizeof(none));
-    hipError_t e = sy::launch_engine(env->p, actions, 1, none, true, env->blocks, env->wpb * 64, env->lds, (hipStream_t)stream);
+    hipError_t e = sy::launch_engine(env->p, actions, 1, none, true, env->blocks, env->wpb, env->lds, (hipStream_t)stream);
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_env_step launch");
 }
 
@@ -180,10 +189,10 @@ int sy_env_rollout(sy_env* env, int32_t T, const sy_rollout_buffers* out, void* 
     sy_rollout_buffers o;
     if (out) o = *out;
     else std::memset(&o, 0, sizeof(o));
-    if (out && (!o.pos || !o.budget || !o.t || !o.action || !o.reward || !o.terminated || !o.truncated || !o.winner))
-        return fail(SY_ERR_INVALID, "sy_env_rollout: only `mask` and `belief` of the record may be NULL%s");
+    if (out && !o.record) return fail(SY_ERR_INVALID, "sy_env_rollout: only `mask` and `belief` of the record may be NULL%s");
+    if (!o.record && (o.mask || o.belief)) return fail(SY_ERR_INVALID, "sy_env_rollout: mask / belief need `record`%s");
     if (o.mask && (reinterpret_cast<uintptr_t>(o.mask) & 15)) return fail(SY_ERR_INVALID, "rollout mask must be 16-byte aligned%s");
-    hipError_t e = sy::launch_engine(env->p, nullptr, T, o, false, env->blocks, env->wpb * 64, env->lds, (hipStream_t)stream);
+    hipError_t e = sy::launch_engine(env->p, nullptr, T, o, false, env->blocks, env->wpb, env->lds, (hipStream_t)stream);
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_env_rollout launch");
 }
 

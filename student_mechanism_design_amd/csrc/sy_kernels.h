@@ -5,7 +5,9 @@
 
 #include "../../include/sy_env.h"
 
-#define SY_LDS_TABLE 256  // exp(-d) / coverage entries staged in LDS per launch block
+#define SY_LDS_TABLE 256   // exp(-d) / coverage / -1/(d+1) entries staged in LDS per launch block
+#define SY_LDS_AVGTAB 512  // -1/(sum/P+1) entries staged in LDS per launch block
+#define SY_RING 16         // move wave -> belief wave ring depth (steps)
 
 namespace sy {
 
@@ -13,7 +15,9 @@ namespace sy {
 struct EngineParams {
     int32_t B, N, NS, P, A, G;
     int32_t money0, max_t, reveal_k, police_ev, belief_onehot, auto_reset;
-    int32_t wave_lds_bytes;       // private LDS slice per wave (belief scratch + mask rows + visits)
+    int32_t wave_lds_bytes;       // private LDS slice per episode (mask rows, visits, belief scratch, ring, sync)
+    int32_t scan_w;               // ELL columns scanned per agent: 8, 12 or 16 (>= widest row of the pool)
+    int32_t rec_words;            // dwords per packed trajectory record (sy_record_words)
     uint32_t seed_lo, seed_hi;    // Philox key
     uint64_t env_id_offset;
     const uint32_t* ell;          // [G][N][16]
@@ -28,9 +32,9 @@ struct EngineParams {
 };
 
 hipError_t launch_engine(const EngineParams& p, const int32_t* actions, int T, const sy_rollout_buffers& out, bool ext,
-                         int blocks, int threads, size_t lds, hipStream_t stream);
+                         int blocks, int wpb, size_t lds, hipStream_t stream);
 hipError_t launch_reset(const EngineParams& p, const uint8_t* env_sel, const int32_t* starts, int zero_count, int blocks,
-                        int threads, size_t lds, hipStream_t stream);
+                        int wpb, size_t lds, hipStream_t stream);
 hipError_t launch_action_mask_dense(const double* adj, const double* wts, const double* tolls, int N, const int32_t* cur,
                                     const double* budget, int Q, uint8_t* mask, hipStream_t stream);
 hipError_t launch_belief_update(const uint32_t* ell, const float* inv_deg, int N, int NS, float* belief, const int32_t* hint,

@@ -1,13 +1,16 @@
 // sy_kernels.hip — hand-written CDNA4 (gfx950) kernels of the batched Scotland-Yard engine.
 //
-// Execution model: ONE 64-lane wavefront per live episode.  A launch block holds `wpb` episodes
-// (waves) that share one board: the board's ELL adjacency (16 packed entries per node) is staged
-// once per block in LDS; every wave owns a private LDS slice for its belief scratch vector, its
-// action-mask rows and its visit counters.  Agent state lives in lanes: lane a holds agent a's
-// node / budget / action (lane 0 = MrX, lane k+1 = Police k).  Membership tests ("is this node a
-// neighbour", "is the target occupied", "is MrX caught") are wave ballots; the sequential move
-// order of the reference (yard.py:161-243) is kept by a wave-uniform loop over v_readlane.
-// No MFMA: this is gather / index work bounded by HBM traffic and LDS issue.
+// Execution model: ONE 64-lane wavefront per live episode for the game dynamics (the "move wave"),
+// plus, in the fused rollout, ONE partner wavefront per episode for the belief filter (the "belief
+// wave") that consumes the episode's positions through a small LDS ring — so at 4096 episodes the
+// chip holds 8 waves per SIMD of two different instruction mixes instead of 4 of one.
+// A launch block holds `wpb` episodes that share one board: the board's ELL adjacency (16 packed
+// entries per node) is staged once per block in LDS together with the reward lookup tables; every
+// episode owns a private LDS slice (mask rows, visit counters, belief scratch, ring).
+// Agent state lives in lanes: lane a holds agent a's node / budget / action (lane 0 = MrX,
+// lane k+1 = Police k).  Membership tests ("is this node a neighbour", "is the target occupied",
+// "is MrX caught") are wave ballots; the sequential move order of the reference (yard.py:161-243)
+// is kept by a wave-uniform loop over v_readlane.  No MFMA: this is gather / index work.
 //
 // Semantics follow the reference file:line cited at each phase (paths under
 // /root/reference/src/environment/).  Compile with -ffp-contract=off: the float64 reward
@@ -19,11 +22,18 @@
 
 namespace sy {
 
+#ifndef SY_ROLLOUT_MIN_WAVES
+#define SY_ROLLOUT_MIN_WAVES 8   // waves per SIMD the rollout kernel is register-budgeted for (2 blocks of 16 waves per CU)
+#endif
+
 static constexpr int kWave = 64;
 static constexpr int kD = SY_ELL_WIDTH;  // 16 ELL entries per node
 static constexpr uint32_t kPurposeAct = 1u, kPurposeReset = 2u;
 static constexpr int kPhiloxRounds = 7;
-static constexpr int kLdsTab = SY_LDS_TABLE;  // exp / coverage table entries staged in LDS
+static constexpr int kLdsTab = SY_LDS_TABLE;   // entries of the exp / coverage / reciprocal tables in LDS
+static constexpr int kAvgTab = SY_LDS_AVGTAB;  // entries of the -1/(sum/P+1) table in LDS
+static constexpr int kRing = SY_RING;          // move wave -> belief wave ring depth (steps)
+static constexpr int kSpinMax = 1 << 20;       // every spin is bounded: a lost partner cannot hang the GPU
 
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wave execute in order; this only stops the compiler from reordering
@@ -53,9 +63,9 @@ __device__ __forceinline__ float wave_sum(float v) {
            __int_as_float(rdlane(iv, 48));
 }
 
-// Philox4x32-7 (Salmon et al. 2011; 7 rounds is the paper's Crush-resistant minimum), word 0.
-__device__ __forceinline__ uint32_t philox_draw(uint64_t gid, uint32_t ctr, uint32_t purpose, uint32_t idx,
-                                                uint32_t k0, uint32_t k1) {
+// Philox4x32-7 (Salmon et al. 2011; 7 rounds is the paper's Crush-resistant minimum).
+__device__ __forceinline__ void philox4(uint64_t gid, uint32_t ctr, uint32_t purpose, uint32_t idx, uint32_t k0,
+                                        uint32_t k1, uint32_t (&o)[4]) {
     uint32_t c0 = (uint32_t)gid, c1 = (uint32_t)(gid >> 32), c2 = ctr, c3 = (purpose << 8) | idx;
 #pragma unroll
     for (int r = 0; r < kPhiloxRounds; ++r) {
@@ -66,13 +76,16 @@ __device__ __forceinline__ uint32_t philox_draw(uint64_t gid, uint32_t ctr, uint
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
-    return c0;
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
 // Distinct start nodes, uniform without replacement (replaces np.random.choice(N, A, replace=False),
-// yard.py:112-116).  All values are wave-uniform; lane a returns agent a's start.
+// yard.py:112-116): draw i = word 0 of philox(env, step_count, RESET, i).  All values are
+// wave-uniform; lane a returns agent a's start.
 __device__ __noinline__ int sample_starts(int lane, int A, int N, uint64_t gid, uint32_t ctr, uint32_t k0, uint32_t k1) {
-    const uint32_t xv = philox_draw(gid, ctr, kPurposeReset, (uint32_t)lane, k0, k1);
+    uint32_t o[4];
+    philox4(gid, ctr, kPurposeReset, (uint32_t)lane, k0, k1, o);
+    const uint32_t xv = o[0];
     int sorted[SY_MAX_AGENTS];
 #pragma unroll
     for (int j = 0; j < SY_MAX_AGENTS; ++j) sorted[j] = 0x7fffffff;
@@ -96,34 +109,53 @@ __device__ __noinline__ int sample_starts(int lane, int A, int N, uint64_t gid, 
     return mine;
 }
 
-// Post-move scan (yard.py:297-317 masks == yard.py:420-472 node sets): 4 agents x 16 ELL entries per
-// pass.  Rebuilds the wave's mask rows in LDS and returns, on lane a, agent a's 16-bit "affordable
-// entry" field and the |possible_moves| count the police position reward uses — which the reference
-// evaluates with agent index i instead of i+1, i.e. the budget of the PREVIOUS agent
-// (reward_calculator.py:190; kept for parity).  Padding entries carry weight 0xFFFF, above any
-// budget the ABI admits, so "affordable" alone identifies real neighbours.
+// Lane -> (agent slot, ELL column) mapping of the neighbour scans.  `gw` ELL columns per agent
+// (8, 12 or 16 — the host picks the smallest that covers the pool's widest row), so 8, 5 or 4
+// agents are scanned per pass: at P = 4 and rows of at most 12 neighbours one pass covers all 5.
+struct ScanMap {
+    int grp, col, sh, per_pass;
+    bool live;
+};
+__device__ __forceinline__ ScanMap make_scan_map(int lane, int gw) {
+    ScanMap m;
+    m.per_pass = gw == 8 ? 8 : (gw == 12 ? 5 : 4);
+    m.grp = gw == 8 ? (lane >> 3) : (gw == 12 ? (lane * 43) >> 9 : (lane >> 4));   // lane / gw for lane < 64
+    m.col = lane - m.grp * gw;
+    m.live = m.grp < m.per_pass;
+    m.sh = (lane % m.per_pass) * gw;   // bit offset of agent (lane)'s field inside a pass ballot
+    return m;
+}
+
+// Post-move scan (yard.py:297-317 masks == yard.py:420-472 node sets).  Rebuilds the wave's mask
+// rows in LDS and returns, on lane a, agent a's "affordable entry" bit field and the
+// |possible_moves| count the police position reward uses — which the reference evaluates with agent
+// index i instead of i+1, i.e. the budget of the PREVIOUS agent (reward_calculator.py:190; kept for
+// parity).  Padding entries carry weight 0xFFFF, above any budget the ABI admits, so "affordable"
+// alone identifies real neighbours.
 __device__ __forceinline__ void scan_masks(const uint32_t* ell_s, uint8_t* mrow, int lane, int A, int NS, int n16,
-                                           int pos_v, int mon_v, uint32_t& aff_field, int& quirk_cnt) {
+                                           int gw, const ScanMap& sm, int pos_v, int mon_v, uint32_t& aff_field,
+                                           int& quirk_cnt) {
     for (int i = lane; i < n16; i += kWave) reinterpret_cast<uint4*>(mrow)[i] = make_uint4(0, 0, 0, 0);
     wave_lds_fence();
     aff_field = 0;
     quirk_cnt = 0;
-    const int d = lane & 15, grp = lane >> 4, sh = (lane & 3) << 4;
-    for (int base = 0; base < A; base += 4) {
-        const int a = base + grp;
-        const int src = a < A ? a : A - 1;
+    const uint32_t fmask = (1u << gw) - 1u;
+    for (int base = 0; base < A; base += sm.per_pass) {
+        const int a = base + sm.grp;
+        const bool on = sm.live && a < A;
+        const int src = on ? a : 0;
         const int pa = bperm(src << 2, pos_v);
         int ma = bperm(src << 2, mon_v);
         const int mq = bperm((src > 0 ? src - 1 : 0) << 2, mon_v);
-        ma = a < A ? ma : -1;
-        const uint32_t ent = ell_s[(pa << 4) | d];
+        ma = on ? ma : -1;
+        const uint32_t ent = ell_s[(pa << 4) | sm.col];
         const int w = (int)(ent >> 16);
         const bool own = w <= ma;
-        const uint64_t bo = __ballot(own), bq = __ballot(w <= mq && a < A);
+        const uint64_t bo = __ballot(own), bq = __ballot(on && w <= mq);
         if (own) mrow[a * NS + (int)(ent & 0xffffu)] = 1;
-        if ((lane >> 2) == (base >> 2)) {
-            aff_field = (uint32_t)(bo >> sh) & 0xffffu;
-            quirk_cnt = __popc((uint32_t)(bq >> sh) & 0xffffu);
+        if (lane >= base && lane < base + sm.per_pass) {
+            aff_field = (uint32_t)(bo >> sm.sh) & fmask;
+            quirk_cnt = __popc((uint32_t)(bq >> sm.sh) & fmask);
         }
     }
     wave_lds_fence();
@@ -131,65 +163,183 @@ __device__ __forceinline__ void scan_masks(const uint32_t* ell_s, uint8_t* mrow,
 
 // Membership test `action in possible_positions` (yard.py:168,218) for caller-given actions:
 // lane a gets ok (affordable neighbour) and the edge cost (yard.py:234-236).
-__device__ __forceinline__ void scan_hits(const uint32_t* ell_s, int lane, int A, int pos_v, int mon_v, int act_v,
-                                          bool& ok, int& cost) {
+__device__ __forceinline__ void scan_hits(const uint32_t* ell_s, int lane, int A, int gw, const ScanMap& sm, int pos_v,
+                                          int mon_v, int act_v, bool& ok, int& cost) {
     ok = false;
     cost = 0;
-    const int d = lane & 15, grp = lane >> 4, sh = (lane & 3) << 4;
-    for (int base = 0; base < A; base += 4) {
-        const int a = base + grp;
-        const int src = a < A ? a : A - 1;
+    const uint32_t fmask = (1u << gw) - 1u;
+    for (int base = 0; base < A; base += sm.per_pass) {
+        const int a = base + sm.grp;
+        const bool on = sm.live && a < A;
+        const int src = on ? a : 0;
         const int pa = bperm(src << 2, pos_v);
         const int ma = bperm(src << 2, mon_v);
         const int aa = bperm(src << 2, act_v);
-        const uint32_t ent = ell_s[(pa << 4) | d];
+        const uint32_t ent = ell_s[(pa << 4) | sm.col];
         const int nbr = (int)(ent & 0xffffu), w = (int)(ent >> 16);
-        const bool hit = (a < A) && (w <= ma) && (nbr == aa);
+        const bool hit = on && (w <= ma) && (nbr == aa);
         const uint64_t bh = __ballot(hit);
-        const uint32_t field = (uint32_t)(bh >> sh) & 0xffffu;
-        const int from = sh + (field ? __ffs((int)field) - 1 : 0);
+        const uint32_t field = (uint32_t)(bh >> sm.sh) & fmask;
+        const int from = sm.sh + (field ? __ffs((int)field) - 1 : 0);
         const int wsel = bperm(from << 2, w);
-        if ((lane >> 2) == (base >> 2)) {
+        if (lane >= base && lane < base + sm.per_pass) {
             ok = field != 0;
             cost = ok ? wsel : 0;
         }
     }
 }
 
+// Moves (yard.py:161-243): MrX first against the PRE-move police, then police strictly in index
+// order, each seeing earlier moves.  tgt_v = wanted node (own node when the action is not a legal
+// move), skipm = ballot of agents that are skipped (-1 / None / no money).
+__device__ __forceinline__ void resolve_moves(int lane, int P, bool is_pol, int tgt_v, uint64_t skipm, int cost_v,
+                                              int& pos_v, int& mon_v) {
+    {
+        const int tgt = rdlane(tgt_v, 0);
+        const bool blocked = __ballot(is_pol && pos_v == tgt) != 0ull;      // :180-188
+        if (!blocked && lane == 0) pos_v = tgt;
+    }
+    for (int k = 1; k <= P; ++k) {
+        const int tgt = rdlane(tgt_v, k);
+        const bool occ = __ballot(is_pol && pos_v == tgt) != 0ull;          // own node included (:231)
+        if (!occ && !((skipm >> k) & 1ull) && lane == k) {
+            pos_v = tgt;
+            mon_v -= cost_v;                                                // :234-236
+        }
+    }
+}
+
+// Reward lookup tables: LDS copies for the fused rollout, global tables for the single step.
+struct RewardTabs {
+    const double* exp_s;   // [kLdsTab + 1] exp(-d); slot kLdsTab holds 0.0
+    const double* cov_s;   // [kLdsTab]     exp(-log1p(v))
+    const double* nrc_s;   // [kLdsTab]     -1/(d+1)
+    const double* nra_s;   // [kAvgTab]     -1/(s/P+1)
+    const double* exp_g;   // global tables (any length)
+    const double* cov_g;
+    int n_exp, n_cov;
+};
+
+__device__ __forceinline__ double exp_neg_slow(const RewardTabs& tb, int d) { return d < tb.n_exp ? tb.exp_g[d] : 0.0; }
+// explicit LDS-address-space read: keeps table lookups on ds_read_b64 (never merged into FLAT loads)
+__device__ __forceinline__ double lds_f64(const double* p) {
+    return *(const __attribute__((address_space(3))) double*)p;
+}
+
+// Per-lane reward coefficients: registers for the single step, a 2x8 LDS table (row 0 = MrX's lane,
+// row 1 = police lanes) for the fused rollout, where registers are what limits waves per SIMD.
+template <bool LDS_TAB>
+struct Coefs {
+    double r[8];
+    const double* s;
+    __device__ __forceinline__ double get(int i) const { return LDS_TAB ? lds_f64(s + i) : r[i]; }
+};
+
+// Shaped rewards (reward_calculator.py:94-266) in float64, reference operation order.
+// Lane 0 = MrX (:126-148), lanes 1..P = police (:182-229).  dm = d(police, MrX), dj[j-1] = d(police, police j).
+// kc[] are per-lane coefficients: lane 0 {w_closest, w_average, w_position, 1-w_time, -, -, -, 0.1},
+// police {w_distance, w_group, w_position, 1-w_time, w_proximity, w_overlap, w_coverage, 0.05}.
+template <bool LDS_TAB>
+__device__ __forceinline__ double shaped_reward(const RewardTabs& tb, int lane, int P, bool is_pol, int t, int qcnt,
+                                                int vc, int dm, const int (&dj)[SY_MAX_AGENTS - 1],
+                                                const Coefs<LDS_TAB>& kc) {
+    int mn = 0x7fffffff, sum = 0;
+    for (int k = 1; k <= P; ++k) {
+        const int dk = rdlane(dm, k);
+        mn = dk < mn ? dk : mn;
+        sum += dk;
+    }
+    // MrX terms: -1/(closest+1), -1/(mean+1)                                   (:140-144)
+    double xa, xb;
+    if (LDS_TAB && mn < kLdsTab && sum < kAvgTab) {
+        xa = lds_f64(tb.nrc_s + mn);
+        xb = lds_f64(tb.nra_s + sum);
+    } else {
+        xa = -1.0 / ((double)mn + 1.0);
+        xb = -1.0 / ((double)sum / (double)P + 1.0);
+    }
+    // police terms: sums over the other police in index order                  (:185-202)
+    double group = 0.0, prox = 0.0;
+    int overlap = 0;
+    int dor = dm | (vc < kLdsTab ? 0 : kLdsTab);   // any value >= 256 sets a bit above bit 7 of the OR
+#pragma unroll
+    for (int j = 1; j < SY_MAX_AGENTS; ++j) dor |= dj[j - 1];
+    double e_mrx, cov;
+    if (LDS_TAB && __ballot(dor >= kLdsTab) == 0ull) {
+        // fast path (wave-uniform): every lookup hits the LDS tables
+#pragma unroll
+        for (int j = 1; j < SY_MAX_AGENTS; ++j) {
+            if (j <= P) {
+                const int dij = dj[j - 1];
+                const bool other = j != lane;
+                const double ex = lds_f64(tb.exp_s + (other ? dij : kLdsTab));   // slot kLdsTab = 0.0: x + 0.0 == x
+                group += ex;
+                prox += dij > 1 ? ex : 0.0;
+                overlap += (other && dij <= 1) ? 1 : 0;
+            }
+        }
+        e_mrx = lds_f64(tb.exp_s + dm);
+        cov = lds_f64(tb.cov_s + vc);
+    } else {
+#pragma unroll
+        for (int j = 1; j < SY_MAX_AGENTS; ++j) {
+            if (j <= P) {
+                const int dij = dj[j - 1];
+                const bool other = j != lane;
+                const double ex = other ? exp_neg_slow(tb, dij) : 0.0;
+                group += ex;
+                prox += dij > 1 ? ex : 0.0;
+                overlap += (other && dij <= 1) ? 1 : 0;
+            }
+        }
+        e_mrx = exp_neg_slow(tb, dm);
+        cov = tb.cov_g[vc < tb.n_cov ? vc : tb.n_cov - 1];                 // :204-207
+    }
+    const double ts = (double)t;
+    const double x0 = lane == 0 ? xa : e_mrx, x1 = lane == 0 ? xb : group;
+    const double base = ((kc.get(0) * x0 + kc.get(1) * x1) + kc.get(2) * (double)qcnt) + kc.get(3) * (kc.get(7) * ts);   // :140-148 / :214-221
+    const double pol = ((base + kc.get(4) * prox) - kc.get(5) * (double)overlap) + kc.get(6) * cov;                      // :222-228
+    return lane == 0 ? base : pol;
+}
+
 // One diffusion + evidence step of the deterministic belief filter (belief_module.py:69-111 in
 // expectation): b' = normalize((b.P) * lik), P[i][j] = adj/deg(i) (row e_i if isolated),
-// reveal -> delta, zero mass -> uniform.  Belief lives in registers (NR slabs of 64 nodes); the
-// scaled vector c = b/deg goes through the wave's LDS slice for the neighbour gathers.  Each slab
-// gathers only as many ELL columns as its widest node has neighbours (rows are filled left to right).
+// zero mass -> uniform.  Belief lives in registers (NR slabs of 64 nodes); the scaled vector
+// c = b/deg goes through the episode's LDS slice for the neighbour gathers.  boff_s holds, per
+// node, 16 uint16 byte offsets (neighbour*4, padding -> the zero slot N*4); each slab gathers only as
+// many 4-entry chunks as its widest node needs (rows are filled left to right).
 template <int NR>
 __device__ __forceinline__ void belief_step(float (&b)[NR], const float (&ideg)[NR], const int (&slab_w)[NR],
-                                            float* c_s, const uint32_t* ell_s, int lane, int N, bool police_ev,
-                                            int pos_v, int P) {
+                                            float* c_s, const uint16_t* boff_s, int lane, int N, bool police_ev,
+                                            const int (&pol)[SY_MAX_AGENTS - 1], int P) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int j = lane + 64 * r;
         if (j < N) c_s[j] = b[r] * ideg[r];
     }
-    if (lane == 0) c_s[N] = 0.0f;  // ELL padding entries point here
+    if (lane == 0) c_s[N] = 0.0f;  // padding entries point here
     wave_lds_fence();
+    const char* cb = reinterpret_cast<const char*>(c_s);
     float tot = 0.0f;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int j = lane + 64 * r;
         const int jj = j < N ? j : N - 1;   // tail lanes read a valid row; their result is discarded
-        const uint4* row = reinterpret_cast<const uint4*>(ell_s + (jj << 4));
+        const uint2* row = reinterpret_cast<const uint2*>(boff_s + (jj << 4));
         float acc = ideg[r] == 0.0f ? b[r] : 0.0f;
         const int wq = slab_w[r];           // wave-uniform number of 4-entry chunks in this slab
         for (int q = 0; q < wq; ++q) {
-            const uint4 v = row[q];
-            acc += c_s[v.x & 0xffffu];
-            acc += c_s[v.y & 0xffffu];
-            acc += c_s[v.z & 0xffffu];
-            acc += c_s[v.w & 0xffffu];
+            const uint2 v = row[q];
+            acc += *reinterpret_cast<const float*>(cb + (v.x & 0xffffu));
+            acc += *reinterpret_cast<const float*>(cb + (v.x >> 16));
+            acc += *reinterpret_cast<const float*>(cb + (v.y & 0xffffu));
+            acc += *reinterpret_cast<const float*>(cb + (v.y >> 16));
         }
-        if (police_ev)
-            for (int k = 1; k <= P; ++k)
-                if (j == rdlane(pos_v, k)) acc = 0.0f;
+        if (police_ev) {
+#pragma unroll
+            for (int k = 0; k < SY_MAX_AGENTS - 1; ++k)
+                if (k < P && j == pol[k]) acc = 0.0f;
+        }
         acc = j < N ? acc : 0.0f;
         b[r] = acc;
         tot += acc;
@@ -205,77 +355,24 @@ __device__ __forceinline__ void belief_step(float (&b)[NR], const float (&ideg)[
     wave_lds_fence();
 }
 
-template <typename T>
-__device__ __forceinline__ T* at_bytes(T* base, uint32_t byte_off) {
-    return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
-}
-
-// ---------------------------------------------------------------------------------------------
-// The engine kernel: T fused env steps per launch.
-//   EXT = true : actions come from the caller (sy_env_step; T == 1).
-//   EXT = false: uniform-random policy inside the kernel (sy_env_rollout), trajectory recorded.
-// LDS: [board ELL N*64 B][exp table 256 f64][coverage table 256 f64][per wave: belief scratch,
-// mask rows, visit counters].
-// ---------------------------------------------------------------------------------------------
-template <int NR, bool EXT, bool REC>
-__global__ __launch_bounds__(1024) void engine_kernel(const EngineParams p, const int32_t* __restrict__ actions,
-                                                      const int T, const sy_rollout_buffers out_arg) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wpb = blockDim.x >> 6;
-    const int N = p.N, NS = p.NS, A = p.A, P = p.P, B = p.B;
-    const int e0 = blockIdx.x * wpb;
-    const int e = e0 + wid;
-
-    uint32_t* ell_s = reinterpret_cast<uint32_t*>(smem);
-    double* exp_s = reinterpret_cast<double*>(smem + (size_t)N * kD * 4);
-    double* cov_s = exp_s + kLdsTab;
-    unsigned char* wbase = reinterpret_cast<unsigned char*>(cov_s + kLdsTab) + (size_t)wid * p.wave_lds_bytes;
-    float* c_s = reinterpret_cast<float*>(wbase);
-    uint8_t* mrow = wbase + (size_t)(NS + 16) * 4;
-    uint16_t* vis_s = reinterpret_cast<uint16_t*>(mrow + (size_t)A * NS);
-
-    // ---- stage the block's board (ELL rows) and the reward tables in LDS: coalesced 16-byte loads
-    int g = p.env_graph[e0 < B ? e0 : B - 1];
-    g = g < 0 ? 0 : (g >= p.G ? p.G - 1 : g);
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(p.ell + (size_t)g * N * kD);
-        uint4* dst = reinterpret_cast<uint4*>(ell_s);
-        for (int i = threadIdx.x; i < N * 4; i += blockDim.x) dst[i] = src[i];
-        for (int i = threadIdx.x; i < kLdsTab; i += blockDim.x) {
-            exp_s[i] = i < p.n_exp ? p.exp_tab[i] : 0.0;
-            cov_s[i] = p.cov_tab[i < p.n_cov ? i : p.n_cov - 1];
-        }
-    }
-    __syncthreads();
-    if (e >= B) return;
-
-    const uint16_t* __restrict__ ap = p.apsp + (size_t)g * N * N;
-    const uint64_t gid = p.env_id_offset + (uint64_t)e;
-    const bool has_belief = p.st.belief != nullptr;
-    const bool is_pol = lane >= 1 && lane <= P;
-    const int n16 = (A * NS) >> 4;
-
-    // per-lane reward coefficients (reward_calculator.py:140-148 for MrX on lane 0, :214-229 for police)
-    const double k0 = lane == 0 ? p.w[4] : p.w[0];
-    const double k1 = lane == 0 ? p.w[5] : p.w[1];
-    const double k2 = lane == 0 ? p.w[6] : p.w[2];
-    const double k3 = 1.0 - (lane == 0 ? p.w[7] : p.w[3]);
-    const double k4 = p.w[9], k5 = p.w[10], k6 = p.w[8];
-
-    // ---- load the episode state: coalesced reads of the batched tensors
-    int pos_v = lane < A ? p.st.pos[(size_t)e * A + lane] : 0;
-    int mon_v = lane < A ? p.st.budget[(size_t)e * A + lane] : 0;
-    int t = p.st.t[e];
-    uint32_t sc = p.st.step_count[e];
-    for (int i = lane; i < (NS >> 3); i += kWave)
-        reinterpret_cast<uint4*>(vis_s)[i] = reinterpret_cast<const uint4*>(p.st.visits + (size_t)e * NS)[i];
-    float b[NR], ideg[NR];
-    int slab_w[NR];
+template <int NR>
+__device__ __forceinline__ void belief_prior(float (&b)[NR], int lane, int N, bool onehot, int m0) {
+    const float uni = 1.0f / (float)N;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int j = lane + 64 * r;
-        b[r] = (has_belief && j < N) ? p.st.belief[(size_t)e * NS + j] : 0.0f;
-        ideg[r] = (has_belief && j < N) ? p.inv_deg[(size_t)g * NS + j] : 0.0f;
+        b[r] = j < N ? (onehot ? (j == m0 ? 1.0f : 0.0f) : uni) : 0.0f;
+    }
+}
+
+template <int NR>
+__device__ __forceinline__ void belief_load(float (&b)[NR], float (&ideg)[NR], int (&slab_w)[NR], const float* bel_row,
+                                            const float* ideg_row, int lane, int N) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = lane + 64 * r;
+        b[r] = j < N ? bel_row[j] : 0.0f;
+        ideg[r] = j < N ? ideg_row[j] : 0.0f;
         // widest row of the slab, in 4-entry chunks (1/deg -> deg is exact for deg <= 16)
         const int deg = ideg[r] > 0.0f ? (int)(1.0f / ideg[r] + 0.5f) : 0;
         int need = (deg + 3) >> 2;
@@ -286,101 +383,395 @@ __global__ __launch_bounds__(1024) void engine_kernel(const EngineParams p, cons
         }
         slab_w[r] = rdlane(need, 0);
     }
-    int rev_ctr = p.reveal_k > 0 ? p.reveal_k - (t % p.reveal_k) : 0;   // steps until the next reveal
-    uint32_t aff = 0;
-    int qcnt = 0;
-    if (!EXT) scan_masks(ell_s, mrow, lane, A, NS, n16, pos_v, mon_v, aff, qcnt);  // rebuild the pre-step masks
+}
 
-    // ---- trajectory cursors: uniform base pointers advanced once per step + constant 32-bit lane offsets
+__device__ __forceinline__ int lds_peek(const int* p) {   // every lane reads the same word: result is wave-uniform
+    return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+}
+__device__ __forceinline__ void lds_poke(int* p, int v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+template <typename T>
+__device__ __forceinline__ T* at_bytes(T* base, uint32_t byte_off) {
+    return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
+}
+template <typename T>
+__device__ __forceinline__ const T* at_bytes(const T* base, uint32_t byte_off) {
+    return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+// LDS carve-up shared by all engine kernels (host mirror: sy_capi.hip::lds_bytes_for).
+struct LdsMap {
+    uint32_t* ell_s;
+    uint16_t* boff_s;
+    double *exp_s, *cov_s, *nrc_s, *nra_s, *kc_s;
+    unsigned char* env_base;   // first per-episode slice
+};
+__device__ __forceinline__ LdsMap lds_map(unsigned char* smem, int N) {
+    LdsMap m;
+    m.ell_s = reinterpret_cast<uint32_t*>(smem);
+    m.boff_s = reinterpret_cast<uint16_t*>(smem + (size_t)N * kD * 4);
+    m.exp_s = reinterpret_cast<double*>(smem + (size_t)N * kD * 6);
+    m.cov_s = m.exp_s + (kLdsTab + 2);
+    m.nrc_s = m.cov_s + kLdsTab;
+    m.nra_s = m.nrc_s + kLdsTab;
+    m.kc_s = m.nra_s + kAvgTab;
+    m.env_base = reinterpret_cast<unsigned char*>(m.kc_s + 16);
+    return m;
+}
+
+// Per-episode LDS slice: [mask rows A*NS][visit counters NS*2][belief scratch (NS+16)*4][ring][sync][record]
+struct EnvLds {
+    uint8_t* mrow;
+    uint16_t* vis_s;
+    float* c_s;
+    int* ring;          // kRing entries of 8 dwords
+    int* sync;          // [0] produced, [1] consumed
+    int* rec_s;         // 64 dwords: one packed trajectory record being assembled
+};
+__device__ __forceinline__ EnvLds env_lds(unsigned char* base, int slot, int slice_bytes, int A, int NS) {
+    EnvLds e;
+    unsigned char* w = base + (size_t)slot * slice_bytes;
+    e.mrow = w;
+    e.vis_s = reinterpret_cast<uint16_t*>(w + (size_t)A * NS);
+    e.c_s = reinterpret_cast<float*>(w + (size_t)A * NS + (size_t)NS * 2);
+    e.ring = reinterpret_cast<int*>(w + (size_t)A * NS + (size_t)NS * 2 + (size_t)(NS + 16) * 4);
+    e.sync = e.ring + kRing * 8;
+    e.rec_s = e.sync + 4;
+    return e;
+}
+
+__device__ __forceinline__ void load_coeffs(const EngineParams& p, int lane, double (&kc)[8]) {
+    // reward_calculator.py:140-148 for MrX on lane 0, :214-229 for police (weights order reward_net.py:5-17)
+    kc[0] = lane == 0 ? p.w[4] : p.w[0];
+    kc[1] = lane == 0 ? p.w[5] : p.w[1];
+    kc[2] = lane == 0 ? p.w[6] : p.w[2];
+    kc[3] = 1.0 - (lane == 0 ? p.w[7] : p.w[3]);
+    kc[4] = p.w[9];
+    kc[5] = p.w[10];
+    kc[6] = p.w[8];
+    kc[7] = lane == 0 ? 0.1 : 0.05;
+}
+
+// Stage the block's board: ELL rows (coalesced 16-byte loads), the belief gather offsets derived
+// from them, and (TABLES) the reward lookup tables.
+template <bool TABLES>
+__device__ __forceinline__ void stage_block(const EngineParams& p, const LdsMap& L, int g, int N) {
+    const uint4* src = reinterpret_cast<const uint4*>(p.ell + (size_t)g * N * kD);
+    uint4* dst = reinterpret_cast<uint4*>(L.ell_s);
+    for (int i = threadIdx.x; i < N * 4; i += blockDim.x) {
+        const uint4 v = src[i];
+        dst[i] = v;
+        uint2 o;
+        o.x = ((v.x & 0xffffu) << 2) | ((v.y & 0xffffu) << 18);
+        o.y = ((v.z & 0xffffu) << 2) | ((v.w & 0xffffu) << 18);
+        reinterpret_cast<uint2*>(L.boff_s)[i] = o;
+    }
+    if (TABLES) {
+        for (int i = threadIdx.x; i < kLdsTab; i += blockDim.x) {
+            L.exp_s[i] = i < p.n_exp ? p.exp_tab[i] : 0.0;
+            L.cov_s[i] = p.cov_tab[i < p.n_cov ? i : p.n_cov - 1];
+            L.nrc_s[i] = -1.0 / ((double)i + 1.0);
+        }
+        if (threadIdx.x == 0) L.exp_s[kLdsTab] = 0.0;
+        for (int i = threadIdx.x; i < kAvgTab; i += blockDim.x) L.nra_s[i] = -1.0 / ((double)i / (double)p.P + 1.0);
+        if (threadIdx.x < 2) {
+            double kc[8];
+            load_coeffs(p, (int)threadIdx.x, kc);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) L.kc_s[threadIdx.x * 8 + i] = kc[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// step_kernel: one env transition with caller-given actions (sy_env_step), one wave per episode.
+// ---------------------------------------------------------------------------------------------
+template <int NR>
+__global__ __launch_bounds__(1024) void step_kernel(const EngineParams p, const int32_t* __restrict__ actions) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+    const int N = p.N, NS = p.NS, A = p.A, P = p.P, B = p.B;
+    const int e0 = blockIdx.x * wpb;
+    const int e = e0 + wid;
+    const LdsMap L = lds_map(smem, N);
+    const EnvLds E = env_lds(L.env_base, wid, p.wave_lds_bytes, A, NS);
+    int g = __builtin_amdgcn_readfirstlane(p.env_graph[e0 < B ? e0 : B - 1]);
+    g = g < 0 ? 0 : (g >= p.G ? p.G - 1 : g);
+    stage_block<false>(p, L, g, N);
+    __syncthreads();
+    if (e >= B) return;
+
+    const uint16_t* __restrict__ ap = p.apsp + (size_t)g * N * N;
+    const bool has_belief = p.st.belief != nullptr;
+    const bool is_pol = lane >= 1 && lane <= P;
+    const int n16 = (A * NS) >> 4;
+    const ScanMap sm = make_scan_map(lane, p.scan_w);
+    Coefs<false> kc;
+    load_coeffs(p, lane, kc.r);
+    kc.s = nullptr;
+    RewardTabs tb;
+    tb.exp_s = tb.cov_s = tb.nrc_s = tb.nra_s = nullptr;
+    tb.exp_g = p.exp_tab; tb.cov_g = p.cov_tab; tb.n_exp = p.n_exp; tb.n_cov = p.n_cov;
+
+    int pos_v = lane < A ? p.st.pos[(size_t)e * A + lane] : 0;
+    int mon_v = lane < A ? p.st.budget[(size_t)e * A + lane] : 0;
+    int t = __builtin_amdgcn_readfirstlane(p.st.t[e]);                       // wave-uniform: keep in SGPRs
+    uint32_t sc = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.st.step_count[e]);
+    const int act_v = lane < A ? actions[(size_t)e * A + lane] : -1;
+    float b[NR], ideg[NR];
+    int slab_w[NR];
+    if (has_belief) belief_load<NR>(b, ideg, slab_w, p.st.belief + (size_t)e * NS, p.inv_deg + (size_t)g * NS, lane, N);
+
+    bool ok_v;
+    int cost_v;
+    scan_hits(L.ell_s, lane, A, p.scan_w, sm, pos_v, mon_v, act_v, ok_v, cost_v);
+    const int tgt_v = ok_v ? act_v : pos_v;                                   // yard.py:168-178, :218-229
+    const uint64_t skipm = __ballot(act_v == -1 || mon_v == 0);               // :210-215
+    resolve_moves(lane, P, is_pol, tgt_v, skipm, cost_v, pos_v, mon_v);
+    const uint64_t polm = ((1ull << P) - 1ull) << 1;
+    const bool no_money = (skipm & polm) == polm;                             // :191,216
+    int vc = 0;
+    if (is_pol) {                                                             // :244-245
+        uint16_t* vp = p.st.visits + (size_t)e * NS + pos_v;
+        vc = (int)*vp + 1;
+        *vp = (uint16_t)vc;
+    }
+    const int mrx = rdlane(pos_v, 0);
+    const int row = pos_v * N;
+    int dm = 0;
+    int dj[SY_MAX_AGENTS - 1];
+#pragma unroll
+    for (int j = 1; j < SY_MAX_AGENTS; ++j) dj[j - 1] = 0;
+    if (is_pol) {
+        dm = (int)ap[row + mrx];
+#pragma unroll
+        for (int j = 1; j < SY_MAX_AGENTS; ++j)
+            if (j <= P) dj[j - 1] = (int)ap[row + rdlane(pos_v, j)];
+    }
+    uint32_t aff;
+    int qcnt;
+    scan_masks(L.ell_s, E.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, aff, qcnt);
+    // outcome priority (reward_calculator.py:63-90), flags shared by all agents
+    const bool captured = __ballot(is_pol && pos_v == mrx) != 0ull;
+    const bool timeout = t > p.max_t;  // pre-increment timestep
+    const int term = (captured || (!timeout && no_money)) ? 1 : 0;
+    const int trunc = (!captured && timeout) ? 1 : 0;
+    const int win = captured ? 1 : ((timeout || no_money) ? 2 : 0);
+    const bool ended = (term | trunc) != 0;
+    double rew;
+    if (ended) rew = captured ? (lane == 0 ? -1.0 : 1.0) : (lane == 0 ? 1.0 : 0.0);
+    else rew = shaped_reward<false>(tb, lane, P, is_pol, t, qcnt, vc, dm, dj, kc);
+    t += 1;   // yard.py:355
+    sc += 1;
+    if (lane < A) p.st.reward[(size_t)e * A + lane] = rew;
+    if (lane == 0) {
+        p.st.terminated[e] = (uint8_t)term;
+        p.st.truncated[e] = (uint8_t)trunc;
+        p.st.winner[e] = (int8_t)win;
+    }
+    if (ended && p.auto_reset) {
+        const int st = sample_starts(lane, A, N, p.env_id_offset + (uint64_t)e, sc, p.seed_lo, p.seed_hi);
+        pos_v = lane < A ? st : 0;
+        mon_v = lane == 0 ? SY_MRX_MONEY : (lane < A ? p.money0 : 0);   // yard.py:117-119
+        t = 0;
+        for (int i = lane; i < (NS >> 3); i += kWave)
+            reinterpret_cast<uint4*>(p.st.visits + (size_t)e * NS)[i] = make_uint4(0, 0, 0, 0);
+        if (has_belief) belief_prior<NR>(b, lane, N, p.belief_onehot != 0, rdlane(pos_v, 0));
+        scan_masks(L.ell_s, E.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, aff, qcnt);
+    } else if (has_belief) {
+        if (p.reveal_k > 0 && (t % p.reveal_k) == 0) {   // post-increment timestep is a multiple of reveal_k
+            belief_prior<NR>(b, lane, N, true, mrx);
+        } else {
+            int pol[SY_MAX_AGENTS - 1];
+#pragma unroll
+            for (int k = 0; k < SY_MAX_AGENTS - 1; ++k) pol[k] = k < P ? rdlane(pos_v, k + 1) : -1;
+            belief_step<NR>(b, ideg, slab_w, E.c_s, L.boff_s, lane, N, p.police_ev != 0, pol, P);
+        }
+    }
+    if (lane < A) {
+        p.st.pos[(size_t)e * A + lane] = pos_v;
+        p.st.budget[(size_t)e * A + lane] = mon_v;
+    }
+    if (lane == 0) {
+        p.st.t[e] = t;
+        p.st.step_count[e] = sc;
+    }
+    {
+        uint4* dst = reinterpret_cast<uint4*>(p.st.mask + (size_t)e * A * NS);
+        for (int i = lane; i < n16; i += kWave) dst[i] = reinterpret_cast<const uint4*>(E.mrow)[i];
+    }
+    if (has_belief) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int j = lane + 64 * r;
+            if (j < NS) p.st.belief[(size_t)e * NS + j] = b[r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rollout_kernel: T fused env steps per launch with the uniform-random policy (sy_env_rollout).
+// Waves [0, wpb) of a block are the move waves of its episodes; when the engine tracks a belief,
+// waves [wpb, 2*wpb) are their belief waves.  Hand-off: after step s the move wave writes one ring
+// entry {MrX node | flags, police nodes} and bumps `produced`; the belief wave records belief s,
+// waits for entry s, applies prior / reveal / diffusion and bumps `consumed`.  LDS operations of a
+// wave are performed in order, so data-then-counter needs no extra wait; all spins are bounded.
+// ---------------------------------------------------------------------------------------------
+template <int NR, bool REC>
+__global__ __launch_bounds__(1024, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(const EngineParams p, const int T, const sy_rollout_buffers out_arg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const bool has_belief = p.st.belief != nullptr;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wpb = (int)(blockDim.x >> 6) >> (has_belief ? 1 : 0);
+    const bool belief_role = wid >= wpb;
+    const int slot = belief_role ? wid - wpb : wid;
+    const int N = p.N, NS = p.NS, A = p.A, P = p.P, B = p.B;
+    const int e0 = blockIdx.x * wpb;
+    const int e = e0 + slot;
+    const LdsMap L = lds_map(smem, N);
+    const EnvLds E = env_lds(L.env_base, slot, p.wave_lds_bytes, A, NS);
+    int g = __builtin_amdgcn_readfirstlane(p.env_graph[e0 < B ? e0 : B - 1]);
+    g = g < 0 ? 0 : (g >= p.G ? p.G - 1 : g);
+    stage_block<true>(p, L, g, N);
+    if (!belief_role && lane == 0) {
+        E.sync[0] = 0;
+        E.sync[1] = 0;
+    }
+    __syncthreads();
+    if (e >= B) return;
     sy_rollout_buffers out = out_arg;
-    const uint32_t off_small = (uint32_t)(e * A + lane) * 4u;
-    const uint32_t off_env = (uint32_t)e;
+
+    if (belief_role) {
+        // ================================ belief wave ================================
+        float b[NR], ideg[NR];
+        int slab_w[NR];
+        belief_load<NR>(b, ideg, slab_w, p.st.belief + (size_t)e * NS, p.inv_deg + (size_t)g * NS, lane, N);
+        const uint32_t off_bel = ((uint32_t)e * (uint32_t)NS + (uint32_t)lane) * 4u;
+        const bool rec_bel = REC && out.belief != nullptr;
+        for (int s = 0; s < T; ++s) {
+            if (rec_bel) {
+#pragma unroll
+                for (int r = 0; r < NR; ++r)
+                    if (lane + 64 * r < NS) *at_bytes(out.belief, off_bel + 256u * r) = b[r];
+                out.belief += (size_t)B * NS;
+            }
+            for (int spin = 0; lds_peek(E.sync) <= s && spin < kSpinMax; ++spin) __builtin_amdgcn_s_sleep(2);
+            asm volatile("" ::: "memory");
+            const int4* ent = reinterpret_cast<const int4*>(E.ring + (s & (kRing - 1)) * 8);
+            const int4 e0v = ent[0], e1v = ent[1];
+            const int head = __builtin_amdgcn_readfirstlane(e0v.x);
+            const int pol[SY_MAX_AGENTS - 1] = {
+                __builtin_amdgcn_readfirstlane(e0v.y), __builtin_amdgcn_readfirstlane(e0v.z),
+                __builtin_amdgcn_readfirstlane(e0v.w), __builtin_amdgcn_readfirstlane(e1v.x),
+                __builtin_amdgcn_readfirstlane(e1v.y), __builtin_amdgcn_readfirstlane(e1v.z),
+                __builtin_amdgcn_readfirstlane(e1v.w)};
+            asm volatile("" ::: "memory");
+            if (lane == 0) lds_poke(E.sync + 1, s + 1);   // entry copied to registers: the slot may be reused
+            const int node = head & 0xffff, flags = head >> 16;
+            if (flags & 1) belief_prior<NR>(b, lane, N, p.belief_onehot != 0, node);      // new episode
+            else if (flags & 2) belief_prior<NR>(b, lane, N, true, node);                  // reveal -> delta
+            else belief_step<NR>(b, ideg, slab_w, E.c_s, L.boff_s, lane, N, p.police_ev != 0, pol, P);
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int j = lane + 64 * r;
+            if (j < NS) p.st.belief[(size_t)e * NS + j] = b[r];
+        }
+        return;
+    }
+
+    // ================================== move wave ==================================
+    const uint16_t* __restrict__ ap = p.apsp + (size_t)g * N * N;
+    const uint64_t gid = p.env_id_offset + (uint64_t)e;
+    const bool is_pol = lane >= 1 && lane <= P;
+    const int n16 = (A * NS) >> 4;
+    const ScanMap sm = make_scan_map(lane, p.scan_w);
+    Coefs<true> kc;
+    kc.s = L.kc_s + (lane == 0 ? 0 : 8);
+    RewardTabs tb;
+    tb.exp_s = L.exp_s; tb.cov_s = L.cov_s; tb.nrc_s = L.nrc_s; tb.nra_s = L.nra_s;
+    tb.exp_g = p.exp_tab; tb.cov_g = p.cov_tab; tb.n_exp = p.n_exp; tb.n_cov = p.n_cov;
+
+    // ---- load the episode state: coalesced reads of the batched tensors
+    int pos_v = lane < A ? p.st.pos[(size_t)e * A + lane] : 0;
+    int mon_v = lane < A ? p.st.budget[(size_t)e * A + lane] : 0;
+    int t = __builtin_amdgcn_readfirstlane(p.st.t[e]);                       // wave-uniform: keep in SGPRs
+    uint32_t sc = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.st.step_count[e]);
+    for (int i = lane; i < (NS >> 3); i += kWave)
+        reinterpret_cast<uint4*>(E.vis_s)[i] = reinterpret_cast<const uint4*>(p.st.visits + (size_t)e * NS)[i];
+    int rev_ctr = p.reveal_k > 0 ? p.reveal_k - (t % p.reveal_k) : 0;   // steps until the next reveal
+    uint32_t aff;
+    int qcnt;
+    scan_masks(L.ell_s, E.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, aff, qcnt);  // pre-step masks
+    uint32_t xw[4];   // action draws of 4 consecutive steps: word (step_count & 3) of philox(env, step_count >> 2, ACT, lane)
+    philox4(gid, sc >> 2, kPurposeAct, (uint32_t)lane, p.seed_lo, p.seed_hi, xw);
+
+    // trajectory cursors: uniform base pointers advanced once per step + constant 32-bit lane offsets.
+    // The per-step record (reward, pos, budget, action, t, flags) is assembled in LDS in its packed
+    // layout and leaves as ONE coalesced store of RW dwords per episode and step.
+    const int RW = p.rec_words;
+    const uint32_t off_rec = ((uint32_t)e * (uint32_t)RW + (uint32_t)lane) * 4u;
     const uint32_t off_mask = (uint32_t)e * (uint32_t)(A * NS) + (uint32_t)lane * 16u;
-    const uint32_t off_bel = ((uint32_t)e * (uint32_t)NS + (uint32_t)lane) * 4u;
     const size_t BA = (size_t)B * A;
+    int* rec_rew = E.rec_s + 2 * lane;            // lane a: reward as two dwords
+    int* rec_pos = E.rec_s + 2 * A + lane;        // lane a: pos / budget / action at +0, +A, +2A
 
     double rew = 0.0;
     int term = 0, trunc = 0, win = 0;
 
     for (int s = 0; s < T; ++s) {
-        // ---- A. actions
-        int act_v = -1, cost_v = 0;
-        bool ok_v = false;
-        if (EXT) {
-            act_v = lane < A ? actions[(size_t)e * A + lane] : -1;
-            scan_hits(ell_s, lane, A, pos_v, mon_v, act_v, ok_v, cost_v);
-        } else {
-            // uniform over the agent's valid mask, -1 when it is empty (random_agent.py)
-            const int k = __popc(aff);
-            const uint32_t x = philox_draw(gid, sc, kPurposeAct, (uint32_t)lane, p.seed_lo, p.seed_hi);
-            const int r = (int)__umulhi(x, (uint32_t)k);
-            uint32_t f = aff;
-            for (int i = 0; i < r; ++i) f &= f - 1;
-            const int bit = f ? __ffs((int)f) - 1 : 0;
-            const uint32_t ent = ell_s[(pos_v << 4) | bit];
-            ok_v = (lane < A) && (k > 0);
-            act_v = ok_v ? (int)(ent & 0xffffu) : -1;
-            cost_v = ok_v ? (int)(ent >> 16) : 0;
-            // ---- B. record the pre-step observation and the action
-            if (REC && lane < A) {
-                *at_bytes(out.pos, off_small) = pos_v;
-                *at_bytes(out.budget, off_small) = mon_v;
-                *at_bytes(out.action, off_small) = act_v;
-            }
-            if (REC && lane == 0) out.t[off_env] = t;
-            if (REC && out.mask) {
-                for (int i = lane; i < n16; i += kWave)
-                    *reinterpret_cast<uint4*>(out.mask + off_mask + (uint32_t)(i - lane) * 16u) =
-                        reinterpret_cast<const uint4*>(mrow)[i];
-            }
-            if (REC && out.belief && has_belief) {
-#pragma unroll
-                for (int r2 = 0; r2 < NR; ++r2)
-                    if (lane + 64 * r2 < NS) *at_bytes(out.belief, off_bel + 256u * r2) = b[r2];
-            }
-        }
-
-        // ---- C. moves.  MrX first against the PRE-move police (yard.py:161-188) ...
-        const int tgt_v = ok_v ? act_v : pos_v;                                   // :168-178, :218-229
+        // ---- A. uniform over the agent's valid mask, -1 when it is empty (random_agent.py)
+        const int k = __popc(aff);
+        const uint32_t m = sc & 3u;
+        const uint32_t x = m == 0 ? xw[0] : (m == 1 ? xw[1] : (m == 2 ? xw[2] : xw[3]));
+        const int r = (int)__umulhi(x, (uint32_t)k);
+        uint32_t f = aff;
+        for (int i = 0; i < r; ++i) f &= f - 1;
+        const int bit = f ? __ffs((int)f) - 1 : 0;
+        const uint32_t ent = L.ell_s[(pos_v << 4) | bit];
+        const bool ok_v = (lane < A) && (k > 0);
+        const int act_v = ok_v ? (int)(ent & 0xffffu) : -1;
+        const int cost_v = ok_v ? (int)(ent >> 16) : 0;
+        // ---- C. moves (yard.py:161-243)
+        const int pos0_v = pos_v, mon0_v = mon_v;   // pre-step observation, recorded below
         const uint64_t skipm = __ballot(act_v == -1 || mon_v == 0);               // :210-215
-        {
-            const int tgt = rdlane(tgt_v, 0);
-            const bool blocked = __ballot(is_pol && pos_v == tgt) != 0ull;
-            if (!blocked && lane == 0) pos_v = tgt;
-        }
-        // ... then police strictly in index order, each seeing earlier moves (yard.py:191-243)
-        for (int k = 1; k <= P; ++k) {
-            const int tgt = rdlane(tgt_v, k);
-            const bool occ = __ballot(is_pol && pos_v == tgt) != 0ull;            // own node included (:231)
-            if (!occ && !((skipm >> k) & 1ull) && lane == k) {
-                pos_v = tgt;
-                mon_v -= cost_v;                                                  // :234-236
-            }
-        }
+        resolve_moves(lane, P, is_pol, act_v >= 0 ? act_v : pos_v, skipm, cost_v, pos_v, mon_v);
         const uint64_t polm = ((1ull << P) - 1ull) << 1;
         const bool no_money = (skipm & polm) == polm;                             // :191,216
         // node_visit_counts (yard.py:244-245): police never share a node, so no conflicts
         int vc = 0;
         if (is_pol) {
-            vc = (int)vis_s[pos_v] + 1;
-            vis_s[pos_v] = (uint16_t)vc;
+            vc = (int)E.vis_s[pos_v] + 1;
+            E.vis_s[pos_v] = (uint16_t)vc;
         }
         const int mrx = rdlane(pos_v, 0);
         // shortest-path lookups for the shaped rewards are issued now and consumed after the scan
-        const int row = pos_v * N;
-        int dm = 0x7fffffff;
+        const uint32_t rowb = (uint32_t)(pos_v * N) * 2u;
+        int dm = 0;
         int dj[SY_MAX_AGENTS - 1];
 #pragma unroll
         for (int j = 1; j < SY_MAX_AGENTS; ++j) dj[j - 1] = 0;
         if (is_pol) {
-            dm = (int)ap[row + mrx];
+            dm = (int)*at_bytes(ap + mrx, rowb);
 #pragma unroll
             for (int j = 1; j < SY_MAX_AGENTS; ++j)
-                if (j <= P) dj[j - 1] = (int)ap[row + rdlane(pos_v, j)];
+                if (j <= P) dj[j - 1] = (int)*at_bytes(ap + rdlane(pos_v, j), rowb);
+        }
+
+        // ---- B. record the pre-step observation and the action.  Issued after the loads above: vector
+        //      memory returns in order, so the reward lookups never queue behind this step's stores.
+        if (REC) {
+            if (out.mask) {
+                for (int i = lane; i < n16; i += kWave)
+                    *reinterpret_cast<uint4*>(out.mask + off_mask + (uint32_t)(i - lane) * 16u) =
+                        reinterpret_cast<const uint4*>(E.mrow)[i];
+            }
         }
 
         // ---- F. post-move scan: masks for the next observation + position-reward counts
-        scan_masks(ell_s, mrow, lane, A, NS, n16, pos_v, mon_v, aff, qcnt);
+        scan_masks(L.ell_s, E.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, aff, qcnt);
 
         // ---- D. outcome priority (reward_calculator.py:63-90), flags shared by all agents
         const bool captured = __ballot(is_pol && pos_v == mrx) != 0ull;
@@ -389,94 +780,49 @@ __global__ __launch_bounds__(1024) void engine_kernel(const EngineParams p, cons
         trunc = (!captured && timeout) ? 1 : 0;
         win = captured ? 1 : ((timeout || no_money) ? 2 : 0);
         const bool ended = (term | trunc) != 0;
-        if (ended) {
-            rew = captured ? (lane == 0 ? -1.0 : 1.0) : (lane == 0 ? 1.0 : 0.0);
-        } else {
-            // shaped rewards (reward_calculator.py:94-266) in float64, reference operation order
-            int mn = 0x7fffffff, sum = 0;
-            for (int k = 1; k <= P; ++k) {
-                const int dk = rdlane(dm, k);
-                mn = dk < mn ? dk : mn;
-                sum += dk;
-            }
-            const double ts = (double)t;
-            const double cntd = (double)qcnt;
-            if (lane == 0) {
-                const double closest = (double)mn, avg = (double)sum / (double)P;
-                rew = ((k0 * (-1.0 / (closest + 1.0)) + k1 * (-1.0 / (avg + 1.0))) + k2 * cntd) + k3 * (0.1 * ts);
-            } else if (is_pol) {
-                double group = 0.0, overlap = 0.0, prox = 0.0;
-#pragma unroll
-                for (int j = 1; j < SY_MAX_AGENTS; ++j) {
-                    if (j <= P && j != lane) {
-                        const int dij = dj[j - 1];
-                        double ex;
-                        if (EXT) ex = dij < p.n_exp ? p.exp_tab[dij] : 0.0;
-                        else ex = dij < kLdsTab ? exp_s[dij] : (dij < p.n_exp ? p.exp_tab[dij] : 0.0);
-                        group += ex;
-                        if (dij <= 1) overlap += 1.0;
-                        else prox += ex;
-                    }
-                }
-                double e_mrx, cov;
-                if (EXT) {
-                    e_mrx = dm < p.n_exp ? p.exp_tab[dm] : 0.0;
-                    cov = p.cov_tab[vc < p.n_cov ? vc : p.n_cov - 1];
-                } else {
-                    e_mrx = dm < kLdsTab ? exp_s[dm] : (dm < p.n_exp ? p.exp_tab[dm] : 0.0);
-                    cov = vc < kLdsTab ? cov_s[vc] : p.cov_tab[vc < p.n_cov ? vc : p.n_cov - 1];
-                }
-                rew = (((((k0 * e_mrx + k1 * group) + k2 * cntd) + k3 * (0.05 * ts)) + k4 * prox) - k5 * overlap) + k6 * cov;
-            }
-        }
+        if (ended) rew = captured ? (lane == 0 ? -1.0 : 1.0) : (lane == 0 ? 1.0 : 0.0);
+        else rew = shaped_reward<true>(tb, lane, P, is_pol, t, qcnt, vc, dm, dj, kc);
         t += 1;   // yard.py:355
         sc += 1;
+        if ((sc & 3u) == 0u) philox4(gid, sc >> 2, kPurposeAct, (uint32_t)lane, p.seed_lo, p.seed_hi, xw);
         if (REC) {
-            if (lane < A) *at_bytes(out.reward, off_small * 2u) = rew;
-            if (lane == 0) {
-                out.terminated[off_env] = (uint8_t)term;
-                out.truncated[off_env] = (uint8_t)trunc;
-                out.winner[off_env] = (int8_t)win;
+            if (lane < A) {
+                rec_rew[0] = __double2loint(rew);
+                rec_rew[1] = __double2hiint(rew);
+                rec_pos[0] = pos0_v;
+                rec_pos[A] = mon0_v;
+                rec_pos[2 * A] = act_v;
             }
-            out.pos += BA; out.budget += BA; out.action += BA; out.reward += BA;
-            out.t += B; out.terminated += B; out.truncated += B; out.winner += B;
+            if (lane < 4) E.rec_s[5 * A + lane] = lane == 0 ? t - 1 : (lane == 1 ? term : (lane == 2 ? trunc : win));
+            wave_lds_fence();
+            if (lane < RW) *at_bytes(out.record, off_rec) = E.rec_s[lane];
+            out.record += (size_t)B * RW;
             if (out.mask) out.mask += BA * NS;
-            if (out.belief) out.belief += (size_t)B * NS;
         }
 
-        // ---- E. next episode (auto-reset) or belief update for the new positions
+        // ---- E. next episode (auto-reset) and the hand-off to the belief wave
+        int flags = 0;
         if (ended && p.auto_reset) {
             const int st = sample_starts(lane, A, N, gid, sc, p.seed_lo, p.seed_hi);
             pos_v = lane < A ? st : 0;
             mon_v = lane == 0 ? SY_MRX_MONEY : (lane < A ? p.money0 : 0);   // yard.py:117-119
             t = 0;
             rev_ctr = p.reveal_k;
-            for (int i = lane; i < (NS >> 3); i += kWave) reinterpret_cast<uint4*>(vis_s)[i] = make_uint4(0, 0, 0, 0);
-            if (has_belief) {
-                const int m0 = rdlane(pos_v, 0);
-                const float uni = 1.0f / (float)N;
-#pragma unroll
-                for (int r = 0; r < NR; ++r) {
-                    const int j = lane + 64 * r;
-                    b[r] = j < N ? (p.belief_onehot ? (j == m0 ? 1.0f : 0.0f) : uni) : 0.0f;
-                }
-            }
+            for (int i = lane; i < (NS >> 3); i += kWave) reinterpret_cast<uint4*>(E.vis_s)[i] = make_uint4(0, 0, 0, 0);
             wave_lds_fence();
-            scan_masks(ell_s, mrow, lane, A, NS, n16, pos_v, mon_v, aff, qcnt);
-        } else {
-            bool reveal = false;
-            if (p.reveal_k > 0 && --rev_ctr == 0) {   // post-increment timestep is a multiple of reveal_k
-                reveal = true;
-                rev_ctr = p.reveal_k;
-            }
-            if (has_belief) {
-                if (reveal) {
-#pragma unroll
-                    for (int r = 0; r < NR; ++r) b[r] = (lane + 64 * r == mrx) ? 1.0f : 0.0f;
-                } else {
-                    belief_step<NR>(b, ideg, slab_w, c_s, ell_s, lane, N, p.police_ev != 0, pos_v, P);
-                }
-            }
+            scan_masks(L.ell_s, E.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, aff, qcnt);
+            flags = 1;
+        } else if (p.reveal_k > 0 && --rev_ctr == 0) {   // post-increment timestep is a multiple of reveal_k
+            rev_ctr = p.reveal_k;
+            flags = 2;
+        }
+        if (has_belief) {
+            for (int spin = 0; s - lds_peek(E.sync + 1) >= kRing && spin < kSpinMax; ++spin) __builtin_amdgcn_s_sleep(2);
+            asm volatile("" ::: "memory");
+            int* slot_p = E.ring + (s & (kRing - 1)) * 8;
+            if (lane < 8) slot_p[lane] = lane == 0 ? (pos_v | (flags << 16)) : (lane <= P ? pos_v : -1);
+            asm volatile("" ::: "memory");
+            if (lane == 0) lds_poke(E.sync, s + 1);
         }
     }
 
@@ -494,45 +840,32 @@ __global__ __launch_bounds__(1024) void engine_kernel(const EngineParams p, cons
         p.st.winner[e] = (int8_t)win;
     }
     for (int i = lane; i < (NS >> 3); i += kWave)
-        reinterpret_cast<uint4*>(p.st.visits + (size_t)e * NS)[i] = reinterpret_cast<const uint4*>(vis_s)[i];
+        reinterpret_cast<uint4*>(p.st.visits + (size_t)e * NS)[i] = reinterpret_cast<const uint4*>(E.vis_s)[i];
     {
         uint4* dst = reinterpret_cast<uint4*>(p.st.mask + (size_t)e * A * NS);
-        for (int i = lane; i < n16; i += kWave) dst[i] = reinterpret_cast<const uint4*>(mrow)[i];
-    }
-    if (has_belief) {
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int j = lane + 64 * r;
-            if (j < NS) p.st.belief[(size_t)e * NS + j] = b[r];
-        }
+        for (int i = lane; i < n16; i += kWave) dst[i] = reinterpret_cast<const uint4*>(E.mrow)[i];
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // reset (yard.py:80-142): new start nodes, budgets, counters, belief, masks.
 // ---------------------------------------------------------------------------------------------
-template <int NR>
 __global__ __launch_bounds__(1024) void reset_kernel(const EngineParams p, const uint8_t* __restrict__ env_sel,
                                                      const int32_t* __restrict__ starts, const int zero_count) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
     const int N = p.N, NS = p.NS, A = p.A, B = p.B;
     const int e0 = blockIdx.x * wpb;
     const int e = e0 + wid;
-    uint32_t* ell_s = reinterpret_cast<uint32_t*>(smem);
-    unsigned char* wbase = smem + (size_t)N * kD * 4 + 2 * kLdsTab * sizeof(double) + (size_t)wid * p.wave_lds_bytes;
-    uint8_t* mrow = wbase + (size_t)(NS + 16) * 4;
-    int g = p.env_graph[e0 < B ? e0 : B - 1];
+    const LdsMap L = lds_map(smem, N);
+    const EnvLds E = env_lds(L.env_base, wid, p.wave_lds_bytes, A, NS);
+    int g = __builtin_amdgcn_readfirstlane(p.env_graph[e0 < B ? e0 : B - 1]);
     g = g < 0 ? 0 : (g >= p.G ? p.G - 1 : g);
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(p.ell + (size_t)g * N * kD);
-        uint4* dst = reinterpret_cast<uint4*>(ell_s);
-        for (int i = threadIdx.x; i < N * 4; i += blockDim.x) dst[i] = src[i];
-    }
+    stage_block<false>(p, L, g, N);
     __syncthreads();
     if (e >= B) return;
-    if (env_sel && !env_sel[e]) return;
-    uint32_t sc = zero_count ? 0u : p.st.step_count[e];
+    if (env_sel && !__builtin_amdgcn_readfirstlane((int)env_sel[e])) return;
+    uint32_t sc = zero_count ? 0u : (uint32_t)__builtin_amdgcn_readfirstlane((int)p.st.step_count[e]);
     int pos_v;
     if (starts) {
         int sv = lane < A ? starts[(size_t)e * A + lane] : 0;
@@ -542,9 +875,10 @@ __global__ __launch_bounds__(1024) void reset_kernel(const EngineParams p, const
         pos_v = lane < A ? st : 0;
     }
     const int mon_v = lane == 0 ? SY_MRX_MONEY : (lane < A ? p.money0 : 0);
+    const ScanMap sm = make_scan_map(lane, p.scan_w);
     uint32_t aff;
     int qcnt;
-    scan_masks(ell_s, mrow, lane, A, NS, (A * NS) >> 4, pos_v, mon_v, aff, qcnt);
+    scan_masks(L.ell_s, E.mrow, lane, A, NS, (A * NS) >> 4, p.scan_w, sm, pos_v, mon_v, aff, qcnt);
     if (lane < A) {
         p.st.pos[(size_t)e * A + lane] = pos_v;
         p.st.budget[(size_t)e * A + lane] = mon_v;
@@ -561,7 +895,7 @@ __global__ __launch_bounds__(1024) void reset_kernel(const EngineParams p, const
         reinterpret_cast<uint4*>(p.st.visits + (size_t)e * NS)[i] = make_uint4(0, 0, 0, 0);
     {
         uint4* dst = reinterpret_cast<uint4*>(p.st.mask + (size_t)e * A * NS);
-        for (int i = lane; i < ((A * NS) >> 4); i += kWave) dst[i] = reinterpret_cast<const uint4*>(mrow)[i];
+        for (int i = lane; i < ((A * NS) >> 4); i += kWave) dst[i] = reinterpret_cast<const uint4*>(E.mrow)[i];
     }
     if (p.st.belief) {
         const int m0 = rdlane(pos_v, 0);
@@ -603,7 +937,7 @@ __global__ __launch_bounds__(256) void belief_update_kernel(const uint32_t* __re
                                                             float* __restrict__ belief, const int32_t* __restrict__ hint,
                                                             int H, const int32_t* __restrict__ reveal, int Q) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
     uint32_t* ell_s = reinterpret_cast<uint32_t*>(smem);
     float* c_s = reinterpret_cast<float*>(smem + (size_t)N * kD * 4) + (size_t)wid * (NS + 16);
     {
@@ -682,30 +1016,30 @@ __global__ __launch_bounds__(256) void belief_update_kernel(const uint32_t* __re
 // ---------------------------------------------------------------------------------------------
 template <int NR>
 static hipError_t launch_engine_nr(const EngineParams& p, const int32_t* actions, int T, const sy_rollout_buffers& out,
-                                   bool ext, int blocks, int threads, size_t lds, hipStream_t stream) {
+                                   bool ext, int blocks, int wpb, size_t lds, hipStream_t stream) {
     if (ext) {
-        hipLaunchKernelGGL((engine_kernel<NR, true, false>), dim3(blocks), dim3(threads), lds, stream, p, actions, T, out);
-    } else if (out.pos) {
-        hipLaunchKernelGGL((engine_kernel<NR, false, true>), dim3(blocks), dim3(threads), lds, stream, p, actions, T, out);
+        hipLaunchKernelGGL((step_kernel<NR>), dim3(blocks), dim3(wpb * 64), lds, stream, p, actions);
     } else {
-        hipLaunchKernelGGL((engine_kernel<NR, false, false>), dim3(blocks), dim3(threads), lds, stream, p, actions, T, out);
+        const int threads = wpb * 64 * (p.st.belief ? 2 : 1);
+        if (out.record) hipLaunchKernelGGL((rollout_kernel<NR, true>), dim3(blocks), dim3(threads), lds, stream, p, T, out);
+        else hipLaunchKernelGGL((rollout_kernel<NR, false>), dim3(blocks), dim3(threads), lds, stream, p, T, out);
     }
     return hipGetLastError();
 }
 
 hipError_t launch_engine(const EngineParams& p, const int32_t* actions, int T, const sy_rollout_buffers& out, bool ext,
-                         int blocks, int threads, size_t lds, hipStream_t stream) {
+                         int blocks, int wpb, size_t lds, hipStream_t stream) {
     const int nr = (p.N + 63) / 64;
-    if (nr <= 1) return launch_engine_nr<1>(p, actions, T, out, ext, blocks, threads, lds, stream);
-    if (nr <= 2) return launch_engine_nr<2>(p, actions, T, out, ext, blocks, threads, lds, stream);
-    if (nr <= 4) return launch_engine_nr<4>(p, actions, T, out, ext, blocks, threads, lds, stream);
-    if (nr <= 8) return launch_engine_nr<8>(p, actions, T, out, ext, blocks, threads, lds, stream);
-    return launch_engine_nr<16>(p, actions, T, out, ext, blocks, threads, lds, stream);
+    if (nr <= 1) return launch_engine_nr<1>(p, actions, T, out, ext, blocks, wpb, lds, stream);
+    if (nr <= 2) return launch_engine_nr<2>(p, actions, T, out, ext, blocks, wpb, lds, stream);
+    if (nr <= 4) return launch_engine_nr<4>(p, actions, T, out, ext, blocks, wpb, lds, stream);
+    if (nr <= 8) return launch_engine_nr<8>(p, actions, T, out, ext, blocks, wpb, lds, stream);
+    return launch_engine_nr<16>(p, actions, T, out, ext, blocks, wpb, lds, stream);
 }
 
 hipError_t launch_reset(const EngineParams& p, const uint8_t* env_sel, const int32_t* starts, int zero_count, int blocks,
-                        int threads, size_t lds, hipStream_t stream) {
-    hipLaunchKernelGGL((reset_kernel<1>), dim3(blocks), dim3(threads), lds, stream, p, env_sel, starts, zero_count);
+                        int wpb, size_t lds, hipStream_t stream) {
+    hipLaunchKernelGGL(reset_kernel, dim3(blocks), dim3(wpb * 64), lds, stream, p, env_sel, starts, zero_count);
     return hipGetLastError();
 }
 

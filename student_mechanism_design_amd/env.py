@@ -98,8 +98,9 @@ class BatchedScotlandYardEnv:
             raise ValueError(f"all envs of one launch block ({self.waves_per_block} consecutive envs) must share a graph")
         self.env_graph_host = env_graph
         self.env_graph = torch.from_numpy(env_graph).to(dev)
+        self.max_degree = int(((self.pool.ell & 0xFFFF) < self.N).sum(axis=2).max())
         _lib.check(self.lib.sy_env_set_graph_pool(self._handle, _ptr(self.ell), _ptr(self.apsp), _ptr(self.inv_deg),
-                                                  _ptr(self.env_graph)), "sy_env_set_graph_pool")
+                                                  _ptr(self.env_graph), self.max_degree), "sy_env_set_graph_pool")
         # ---- reward weights + tables
         exp_tab, cov_tab = reward_tables()
         self.exp_tab = torch.from_numpy(exp_tab).to(dev)
@@ -209,19 +210,20 @@ class BatchedScotlandYardEnv:
         return self.observation(), self.reward, self.terminated, self.truncated
 
     def alloc_rollout(self, T: int, record_mask=True, record_belief=True) -> Dict[str, torch.Tensor]:
+        """Device buffers of one rollout.  `record` is the packed [T, B, RW] int32 tensor the engine
+        writes with one store per env-step (include/sy_env.h); the named entries are views of it."""
         B, A, NS, dev = self.B, self.A, self.NS, self.device
+        RW = int(self.lib.sy_record_words(A))
+        rec = torch.zeros((T, B, RW), dtype=torch.int32, device=dev)
         buf = {
-            "pos": torch.empty((T, B, A), dtype=torch.int32, device=dev),
-            "budget": torch.empty((T, B, A), dtype=torch.int32, device=dev),
-            "t": torch.empty((T, B), dtype=torch.int32, device=dev),
-            "action": torch.empty((T, B, A), dtype=torch.int32, device=dev),
+            "record": rec,
+            "reward": rec[..., : 2 * A].view(torch.float64),
+            "pos": rec[..., 2 * A: 3 * A], "budget": rec[..., 3 * A: 4 * A], "action": rec[..., 4 * A: 5 * A],
+            "t": rec[..., 5 * A], "terminated": rec[..., 5 * A + 1], "truncated": rec[..., 5 * A + 2],
+            "winner": rec[..., 5 * A + 3],
             "mask": torch.empty((T, B, A, NS), dtype=torch.uint8, device=dev) if record_mask else None,
             "belief": torch.empty((T, B, NS), dtype=torch.float32, device=dev)
             if (record_belief and self._belief is not None) else None,
-            "reward": torch.empty((T, B, A), dtype=torch.float64, device=dev),
-            "terminated": torch.empty((T, B), dtype=torch.uint8, device=dev),
-            "truncated": torch.empty((T, B), dtype=torch.uint8, device=dev),
-            "winner": torch.empty((T, B), dtype=torch.int8, device=dev),
         }
         return buf
 
@@ -232,8 +234,8 @@ class BatchedScotlandYardEnv:
             out = self.alloc_rollout(T, record_mask, record_belief)
         rb = None
         if record:
-            rb = _lib.RolloutBuffers(*[out[k].data_ptr() if out.get(k) is not None else None for k in (
-                "pos", "budget", "t", "action", "mask", "belief", "reward", "terminated", "truncated", "winner")])
+            rb = _lib.RolloutBuffers(*[out[k].data_ptr() if out.get(k) is not None else None
+                                       for k in ("record", "mask", "belief")])
         _lib.check(self.lib.sy_env_rollout(self._handle, int(T), C.byref(rb) if rb is not None else None,
                                            _stream_handle(self.device)), "sy_env_rollout")
         return out

@@ -87,6 +87,7 @@ int sy_env_create(const sy_env_config* c, sy_env** out) {
         return fail(SY_ERR_INVALID, "board does not fit in LDS%s");
     }
     e->wpb = wpb;
+    p.wpb = wpb;
     e->blocks = (p.B + wpb - 1) / wpb;
     e->lds = ell_bytes + (size_t)wpb * p.wave_lds_bytes;
     *out = e;

@@ -18,6 +18,7 @@ struct EngineParams {
     int32_t wave_lds_bytes;       // private LDS slice per episode (mask rows, visits, belief scratch, ring, sync)
     int32_t scan_w;               // ELL columns scanned per agent: 8, 12 or 16 (>= widest row of the pool)
     int32_t rec_words;            // dwords per packed trajectory record (sy_record_words)
+    int32_t wpb;                  // episodes (move waves) per launch block
     uint32_t seed_lo, seed_hi;    // Philox key
     uint64_t env_id_offset;
     const uint32_t* ell;          // [G][N][16]

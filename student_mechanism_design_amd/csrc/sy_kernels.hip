@@ -23,7 +23,7 @@
 namespace sy {
 
 #ifndef SY_ROLLOUT_MIN_WAVES
-#define SY_ROLLOUT_MIN_WAVES 8   // waves per SIMD the rollout kernel is register-budgeted for (2 blocks of 16 waves per CU)
+#define SY_ROLLOUT_MIN_WAVES 6   // waves per SIMD the rollout kernel is register-budgeted for (2 blocks of 12 waves per CU)
 #endif
 
 static constexpr int kWave = 64;
@@ -648,13 +648,13 @@ __global__ __launch_bounds__(1024) void step_kernel(const EngineParams p, const 
 // wave are performed in order, so data-then-counter needs no extra wait; all spins are bounded.
 // ---------------------------------------------------------------------------------------------
 template <int NR, bool REC, int PT>   // PT > 0: police count fixed at compile time (loops over police fully unrolled)
-__global__ __launch_bounds__(1024, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(const EngineParams p, const int T, const sy_rollout_buffers out_arg) {
+__global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(const EngineParams p, const int T, const sy_rollout_buffers out_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const bool has_belief = p.st.belief != nullptr;
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wpb = (int)(blockDim.x >> 6) >> (has_belief ? 1 : 0);
-    const bool belief_role = wid >= wpb;
-    const int slot = belief_role ? wid - wpb : wid;
+    const int wpb = p.wpb;                          // move waves (= episodes) per block
+    const bool belief_role = wid >= wpb;            // belief wave k serves episodes 2k and 2k+1 of the block
+    const int slot = belief_role ? 2 * (wid - wpb) : wid;
     const int P = PT > 0 ? PT : p.P, A = P + 1;
     const int N = p.N, NS = p.NS, B = p.B;
     const int e0 = blockIdx.x * wpb;
@@ -674,40 +674,59 @@ __global__ __launch_bounds__(1024, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(con
 
     if (belief_role) {
         // ================================ belief wave ================================
-        float b[NR], ideg[NR];
+        // serves two episodes (slots `slot`, `slot+1`): a belief step is less than half a move step,
+        // so 1.5 waves per episode keep the chip at 6 waves per SIMD with 80 VGPRs each.
+        const bool live1 = (slot + 1 < wpb) && (e + 1 < B);
+        const EnvLds E1 = env_lds(L.env_base, live1 ? slot + 1 : slot, p.wave_lds_bytes, A, NS);
+        float b0[NR], b1[NR], ideg[NR];
         int slab_w[NR];
-        belief_load<NR>(b, ideg, slab_w, p.st.belief + (size_t)e * NS, p.inv_deg + (size_t)g * NS, lane, N);
+        belief_load<NR>(b0, ideg, slab_w, p.st.belief + (size_t)e * NS, p.inv_deg + (size_t)g * NS, lane, N);
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int j = lane + 64 * r;
+            b1[r] = (live1 && j < N) ? p.st.belief[(size_t)(e + 1) * NS + j] : 0.0f;
+        }
         const uint32_t off_bel = ((uint32_t)e * (uint32_t)NS + (uint32_t)lane) * 4u;
         const bool rec_bel = REC && out.belief != nullptr;
+        const bool onehot = p.belief_onehot != 0, pol_ev = p.police_ev != 0;
         for (int s = 0; s < T; ++s) {
-            if (rec_bel) {
 #pragma unroll
-                for (int r = 0; r < NR; ++r)
-                    if (lane + 64 * r < NS) *at_bytes(out.belief, off_bel + 256u * r) = b[r];
-                out.belief += (size_t)B * NS;
+            for (int h = 0; h < 2; ++h) {
+                if (h == 1 && !live1) break;
+                float (&b)[NR] = h == 0 ? b0 : b1;
+                const EnvLds& Eh = h == 0 ? E : E1;
+                if (rec_bel) {
+#pragma unroll
+                    for (int r = 0; r < NR; ++r)
+                        if (lane + 64 * r < NS) *at_bytes(out.belief, off_bel + (uint32_t)(h * NS) * 4u + 256u * r) = b[r];
+                }
+                for (int spin = 0; lds_peek(Eh.sync) <= s && spin < kSpinMax; ++spin) __builtin_amdgcn_s_sleep(2);
+                asm volatile("" ::: "memory");
+                const int4* ent = reinterpret_cast<const int4*>(Eh.ring + (s & (kRing - 1)) * 8);
+                const int4 e0v = ent[0], e1v = ent[1];
+                const int head = __builtin_amdgcn_readfirstlane(e0v.x);
+                const int pol[SY_MAX_AGENTS - 1] = {
+                    __builtin_amdgcn_readfirstlane(e0v.y), __builtin_amdgcn_readfirstlane(e0v.z),
+                    __builtin_amdgcn_readfirstlane(e0v.w), __builtin_amdgcn_readfirstlane(e1v.x),
+                    __builtin_amdgcn_readfirstlane(e1v.y), __builtin_amdgcn_readfirstlane(e1v.z),
+                    __builtin_amdgcn_readfirstlane(e1v.w)};
+                asm volatile("" ::: "memory");
+                if (lane == 0) lds_poke(Eh.sync + 1, s + 1);   // entry copied to registers: the slot may be reused
+                const int node = head & 0xffff, flags = head >> 16;
+                if (flags & 1) belief_prior<NR>(b, lane, N, onehot, node);          // new episode
+                else if (flags & 2) belief_prior<NR>(b, lane, N, true, node);       // reveal -> delta
+                else belief_step<NR>(b, ideg, slab_w, Eh.c_s, L.boff_s, lane, N, pol_ev, pol, P);
             }
-            for (int spin = 0; lds_peek(E.sync) <= s && spin < kSpinMax; ++spin) __builtin_amdgcn_s_sleep(2);
-            asm volatile("" ::: "memory");
-            const int4* ent = reinterpret_cast<const int4*>(E.ring + (s & (kRing - 1)) * 8);
-            const int4 e0v = ent[0], e1v = ent[1];
-            const int head = __builtin_amdgcn_readfirstlane(e0v.x);
-            const int pol[SY_MAX_AGENTS - 1] = {
-                __builtin_amdgcn_readfirstlane(e0v.y), __builtin_amdgcn_readfirstlane(e0v.z),
-                __builtin_amdgcn_readfirstlane(e0v.w), __builtin_amdgcn_readfirstlane(e1v.x),
-                __builtin_amdgcn_readfirstlane(e1v.y), __builtin_amdgcn_readfirstlane(e1v.z),
-                __builtin_amdgcn_readfirstlane(e1v.w)};
-            asm volatile("" ::: "memory");
-            if (lane == 0) lds_poke(E.sync + 1, s + 1);   // entry copied to registers: the slot may be reused
-            const int node = head & 0xffff, flags = head >> 16;
-            if (flags & 1) belief_prior<NR>(b, lane, N, p.belief_onehot != 0, node);      // new episode
-            else if (flags & 2) belief_prior<NR>(b, lane, N, true, node);                  // reveal -> delta
-            else belief_step<NR>(b, ideg, slab_w, E.c_s, L.boff_s, lane, N, p.police_ev != 0, pol, P);
+            if (rec_bel) out.belief += (size_t)B * NS;
         }
         float* bel_out = kernarg_params()->st.belief;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int j = lane + 64 * r;
-            if (j < NS) bel_out[(size_t)e * NS + j] = b[r];
+            if (j < NS) {
+                bel_out[(size_t)e * NS + j] = b0[r];
+                if (live1) bel_out[(size_t)(e + 1) * NS + j] = b1[r];
+            }
         }
         return;
     }
@@ -1056,7 +1075,7 @@ static hipError_t launch_engine_nr(const EngineParams& p, const int32_t* actions
     if (ext) {
         hipLaunchKernelGGL((step_kernel<NR>), dim3(blocks), dim3(wpb * 64), lds, stream, p, actions);
     } else {
-        const int threads = wpb * 64 * (p.st.belief ? 2 : 1);
+        const int threads = 64 * (wpb + (p.st.belief ? (wpb + 1) / 2 : 0));   // move waves + one belief wave per 2 episodes
 #define SY_LAUNCH_ROLLOUT(PT_)                                                                                            \
     do {                                                                                                                  \
         if (out.record)                                                                                                   \

@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libsy_env.so")
+LIB_PATH = os.environ.get("SY_ENGINE_LIB") or os.path.join(HERE, "libsy_env.so")  # SY_ENGINE_LIB: diagnostic builds
 
 ELL_WIDTH = 16
 MAX_AGENTS = 8

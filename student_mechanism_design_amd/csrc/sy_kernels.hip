@@ -322,43 +322,50 @@ __device__ __forceinline__ void belief_step(float (&b)[NR], const float (&ideg)[
     wave_lds_fence();
     const char* cb = reinterpret_cast<const char*>(c_s);
     auto ld = [cb](uint32_t off) { return *reinterpret_cast<const float*>(cb + off); };
+    // Software-pipelined over the slabs: all offset rows first, then every slab's first eight
+    // gathers (padding entries read the zero slot), then the sums — three LDS round trips per step
+    // instead of three per slab.  Rows wider than 8 neighbours take the second pass below.
+    constexpr int GR = NR < 4 ? NR : 4;     // slabs pipelined together (register budget: 8 gathers each)
     float tot = 0.0f;
 #pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int j = lane + 64 * r;
-        const int jj = j < N ? j : N - 1;   // tail lanes read a valid row; their result is discarded
-        const uint4* row = reinterpret_cast<const uint4*>(boff_s + (jj << 4));
-        const int wq = slab_w[r];           // wave-uniform number of 4-entry chunks this slab needs (0..4)
-        float acc = ideg[r] == 0.0f ? b[r] : 0.0f;
-        if (wq > 0) {
-            // entries 0..7: eight independent gathers in flight, summed as a tree
-            const uint4 o = row[0];
-            const float g0 = ld(o.x & 0xffffu), g1 = ld(o.x >> 16), g2 = ld(o.y & 0xffffu), g3 = ld(o.y >> 16);
-            float s47 = 0.0f;
-            if (wq > 1) {
-                const float g4 = ld(o.z & 0xffffu), g5 = ld(o.z >> 16), g6 = ld(o.w & 0xffffu), g7 = ld(o.w >> 16);
-                s47 = (g4 + g5) + (g6 + g7);
-            }
-            acc += ((g0 + g1) + (g2 + g3)) + s47;
-            if (wq > 2) {
-                const uint4 o2 = row[1];
-                const float h0 = ld(o2.x & 0xffffu), h1 = ld(o2.x >> 16), h2 = ld(o2.y & 0xffffu), h3 = ld(o2.y >> 16);
-                float t47 = 0.0f;
-                if (wq > 3) {
-                    const float h4 = ld(o2.z & 0xffffu), h5 = ld(o2.z >> 16), h6 = ld(o2.w & 0xffffu), h7 = ld(o2.w >> 16);
-                    t47 = (h4 + h5) + (h6 + h7);
-                }
-                acc += ((h0 + h1) + (h2 + h3)) + t47;
-            }
-        }
-        if (police_ev) {
+    for (int r0 = 0; r0 < NR; r0 += GR) {
+        uint4 o[GR];
+        int jr[GR];
 #pragma unroll
-            for (int k = 0; k < SY_MAX_AGENTS - 1; ++k)
-                if (k < P && j == pol[k]) acc = 0.0f;
+        for (int q = 0; q < GR; ++q) {
+            const int j = lane + 64 * (r0 + q);
+            jr[q] = j < N ? j : N - 1;          // tail lanes read a valid row; their result is discarded
+            o[q] = *reinterpret_cast<const uint4*>(boff_s + (jr[q] << 4));
         }
-        acc = j < N ? acc : 0.0f;
-        b[r] = acc;
-        tot += acc;
+        float g[GR][8];
+#pragma unroll
+        for (int q = 0; q < GR; ++q) {
+            g[q][0] = ld(o[q].x & 0xffffu); g[q][1] = ld(o[q].x >> 16);
+            g[q][2] = ld(o[q].y & 0xffffu); g[q][3] = ld(o[q].y >> 16);
+            g[q][4] = ld(o[q].z & 0xffffu); g[q][5] = ld(o[q].z >> 16);
+            g[q][6] = ld(o[q].w & 0xffffu); g[q][7] = ld(o[q].w >> 16);
+        }
+#pragma unroll
+        for (int q = 0; q < GR; ++q) {
+            const int r = r0 + q;
+            const int j = lane + 64 * r;
+            float acc = ideg[r] == 0.0f ? b[r] : 0.0f;
+            acc += ((g[q][0] + g[q][1]) + (g[q][2] + g[q][3])) + ((g[q][4] + g[q][5]) + (g[q][6] + g[q][7]));
+            if (slab_w[r] > 2) {            // wave-uniform: some row of this slab has more than 8 neighbours
+                const uint4 o2 = *reinterpret_cast<const uint4*>(boff_s + (jr[q] << 4) + 8);
+                const float h0 = ld(o2.x & 0xffffu), h1 = ld(o2.x >> 16), h2 = ld(o2.y & 0xffffu), h3 = ld(o2.y >> 16);
+                const float h4 = ld(o2.z & 0xffffu), h5 = ld(o2.z >> 16), h6 = ld(o2.w & 0xffffu), h7 = ld(o2.w >> 16);
+                acc += ((h0 + h1) + (h2 + h3)) + ((h4 + h5) + (h6 + h7));
+            }
+            if (police_ev) {
+#pragma unroll
+                for (int k = 0; k < SY_MAX_AGENTS - 1; ++k)
+                    if (k < P && j == pol[k]) acc = 0.0f;
+            }
+            acc = j < N ? acc : 0.0f;
+            b[r] = acc;
+            tot += acc;
+        }
     }
     tot = wave_sum(tot);
     const float uni = 1.0f / (float)N;

@@ -42,7 +42,7 @@ def cpu_baseline(args, boards, weights, A):
     of the same workload: the same boards / sizes, T_cpu fused steps of B envs."""
     from oracle import oracle_lib as ol
     import student_mechanism_design_amd as sy
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     graphs = [ol.OracleGraph(args.nodes, b.edge_links, b.edges.astype(np.int32)) for b in boards]
     B = args.envs
     per = -(-B // len(graphs))
@@ -169,7 +169,7 @@ def main():
         "env_steps_per_s": value / A,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "engine_kernel<4,false> (fused rollout)", "kernel_ms": kern_ms,
+                     "kernel": "sy::rollout_kernel<4,true,4> (fused rollout, move + belief waves)", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_env_step": R + W, "algorithmic_read_bytes_per_env_step": R,
                      "read_only_frac": (R * T * B / (kern_ms * 1e-3) / 1e9) / HBM_PEAK_GBS},
     }

@@ -52,6 +52,13 @@ syo_graph *syo_graph_create(int32_t N, int32_t E, const int32_t *links, const in
                 g->dist[(size_t)u * N + v] = g->wmin[(size_t)u * N + v];
             }
     }
+    /* neighbour lists (ascending), so the batched engine does not rescan dense rows every step */
+    g->nbr_start = (int32_t *)calloc((size_t)N + 1, sizeof(int32_t));
+    for (int32_t u = 0; u < N; ++u) g->nbr_start[u + 1] = g->nbr_start[u] + g->deg[u];
+    g->nbr = (int32_t *)malloc(sizeof(int32_t) * (size_t)(g->nbr_start[N] > 0 ? g->nbr_start[N] : 1));
+    for (int32_t u = 0, k = 0; u < N; ++u)
+        for (int32_t v = 0; v < N; ++v)
+            if (g->wmin[(size_t)u * N + v] >= 0) g->nbr[k++] = v;
     /* pathfinding.py:34-137 is textbook Dijkstra on integer weights; all-pairs Floyd-Warshall gives
      * the same distances (exact integers). */
     for (int32_t k = 0; k < N; ++k)
@@ -71,6 +78,8 @@ void syo_graph_destroy(syo_graph *g) {
     free(g->wmin);
     free(g->dist);
     free(g->deg);
+    free(g->nbr_start);
+    free(g->nbr);
     free(g);
 }
 
@@ -81,9 +90,10 @@ const int32_t *syo_graph_wmin(const syo_graph *g) { return g->wmin; }
 int32_t syo_possible_moves(const syo_graph *g, int32_t pos, int64_t money, int32_t *nodes, int32_t *weights) {
     int32_t k = 0;
     if (pos < 0 || pos >= g->N) return 0;
-    for (int32_t v = 0; v < g->N; ++v) {
-        int32_t w = g->wmin[(size_t)pos * g->N + v];
-        if (w >= 0 && (int64_t)w <= money) { /* `edges <= agent_money`, yard.py:443-444 */
+    for (int32_t q = g->nbr_start[pos]; q < g->nbr_start[pos + 1]; ++q) {
+        const int32_t v = g->nbr[q];
+        const int32_t w = g->wmin[(size_t)pos * g->N + v];
+        if ((int64_t)w <= money) { /* `edges <= agent_money`, yard.py:443-444 */
             if (nodes) nodes[k] = v;
             if (weights) weights[k] = w;
             ++k;
@@ -121,9 +131,9 @@ void syo_env_masks(const syo_graph *g, int32_t P, const int32_t *pos, const int3
     for (int32_t a = 0; a <= P; ++a) {
         uint8_t *m = masks + (size_t)a * stride;
         memset(m, 0, (size_t)stride);
-        for (int32_t v = 0; v < g->N; ++v) {
-            int32_t w = g->wmin[(size_t)pos[a] * g->N + v];
-            if (w >= 0 && w <= money[a]) m[v] = 1;
+        for (int32_t q = g->nbr_start[pos[a]]; q < g->nbr_start[pos[a] + 1]; ++q) {
+            const int32_t v = g->nbr[q];
+            if (g->wmin[(size_t)pos[a] * g->N + v] <= money[a]) m[v] = 1;
         }
     }
 }
@@ -259,8 +269,10 @@ void syo_belief_update(const syo_graph *g, double *b, const int32_t *hint, int32
     /* :91-98: each particle hops to a uniformly chosen neighbour; stays only when isolated */
     for (int32_t j = 0; j < N; ++j) {
         double acc = g->deg[j] == 0 ? b[j] : 0.0;
-        for (int32_t i = 0; i < N; ++i)
-            if (g->wmin[(size_t)i * N + j] >= 0) acc += b[i] / (double)g->deg[i];
+        for (int32_t q = g->nbr_start[j]; q < g->nbr_start[j + 1]; ++q) { /* undirected: in-neighbours == neighbours */
+            const int32_t i = g->nbr[q];
+            acc += b[i] / (double)g->deg[i];
+        }
         nb[j] = acc;
     }
     if (n_hint > 0) { /* :102-105: likelihood 0.1 + 0.9*hint_mask */

@@ -40,6 +40,7 @@ typedef struct syo_graph {
     int32_t *wmin; /* [N*N] min weight of an edge u-v, -1 = no edge            */
     int32_t *dist; /* [N*N] weighted shortest path, SYO_INF = unreachable      */
     int32_t *deg;  /* [N]   number of distinct neighbours                      */
+    int32_t *nbr_start, *nbr; /* CSR neighbour lists, ascending               */
 } syo_graph;
 
 /* graph from the reference's board arrays (edge_links int32[E][2], edges[E]); NULL on bad input

@@ -114,6 +114,8 @@ __device__ __noinline__ int sample_starts(int lane, int A, int N, uint64_t gid, 
 // agents are scanned per pass: at P = 4 and rows of at most 12 neighbours one pass covers all 5.
 struct ScanMap {
     int grp, col, sh, per_pass;
+    int gsh;            // bit offset of this lane's group inside a pass ballot
+    uint32_t lowmask;   // bits of the group's field below this lane's column
     bool live;
 };
 __device__ __forceinline__ ScanMap make_scan_map(int lane, int gw) {
@@ -123,6 +125,8 @@ __device__ __forceinline__ ScanMap make_scan_map(int lane, int gw) {
     m.col = lane - m.grp * gw;
     m.live = m.grp < m.per_pass;
     m.sh = (lane % m.per_pass) * gw;   // bit offset of agent (lane)'s field inside a pass ballot
+    m.gsh = m.live ? m.grp * gw : 0;
+    m.lowmask = (1u << m.col) - 1u;
     return m;
 }
 
@@ -156,6 +160,50 @@ __device__ __forceinline__ void scan_masks(const uint32_t* ell_s, uint8_t* mrow,
         if (own) mrow[a * NS + (int)(ent & 0xffffu)] = 1;
         if (lane >= base && lane < base + sm.per_pass) {
             aff_field = (uint32_t)(bo >> sm.sh) & fmask;
+            quirk_cnt = __popc((uint32_t)(bq >> sm.sh) & fmask);
+        }
+    }
+    wave_lds_fence();
+}
+
+// scan_masks plus the uniform-random policy (random_agent.py) for the NEXT step, decided inside the
+// scan: a scan lane is chosen when it is affordable and its rank among its agent's affordable
+// entries equals r = mulhi(draw, count) — i.e. the r-th legal neighbour in ascending node order.
+// Lane a returns the sampled action (-1 if the mask is empty) and its edge cost.
+__device__ __forceinline__ void scan_sample(const uint32_t* ell_s, uint8_t* mrow, int lane, int A, int NS, int n16,
+                                            int gw, const ScanMap& sm, int pos_v, int mon_v, uint32_t x_v,
+                                            int& act_v, int& cost_v, int& quirk_cnt) {
+    for (int base16 = 0; base16 < n16; base16 += kWave)   // wave-uniform trip count
+        if (base16 + lane < n16) reinterpret_cast<uint4*>(mrow)[base16 + lane] = make_uint4(0, 0, 0, 0);
+    wave_lds_fence();
+    act_v = -1;
+    cost_v = 0;
+    quirk_cnt = 0;
+    const uint32_t fmask = (1u << gw) - 1u;
+    for (int base = 0; base < A; base += sm.per_pass) {
+        const int a = base + sm.grp;
+        const bool on = sm.live && a < A;
+        const int src = on ? a : 0;
+        const int pa = bperm(src << 2, pos_v);
+        int ma = bperm(src << 2, mon_v);
+        const int mq = bperm((src > 0 ? src - 1 : 0) << 2, mon_v);
+        const uint32_t xa = (uint32_t)bperm(src << 2, (int)x_v);
+        ma = on ? ma : -1;
+        const uint32_t ent = ell_s[(pa << 4) | sm.col];
+        const int w = (int)(ent >> 16);
+        const bool own = w <= ma;
+        const uint64_t bo = __ballot(own), bq = __ballot(on && w <= mq);
+        if (own) mrow[a * NS + (int)(ent & 0xffffu)] = 1;
+        const uint32_t gfield = (uint32_t)(bo >> sm.gsh) & fmask;           // this lane's agent's affordable entries
+        const int rr = (int)__umulhi(xa, (uint32_t)__popc(gfield));
+        const bool chosen = own && __popc(gfield & sm.lowmask) == rr;
+        const uint64_t bc = __ballot(chosen);
+        const uint32_t cf = (uint32_t)(bc >> sm.sh) & fmask;                // agent (lane)'s chosen column, one-hot
+        const int from = sm.sh + (cf ? __ffs((int)cf) - 1 : 0);
+        const uint32_t esel = (uint32_t)bperm(from << 2, (int)ent);
+        if (lane >= base && lane < base + sm.per_pass) {
+            act_v = cf ? (int)(esel & 0xffffu) : -1;
+            cost_v = cf ? (int)(esel >> 16) : 0;
             quirk_cnt = __popc((uint32_t)(bq >> sm.sh) & fmask);
         }
     }
@@ -206,6 +254,41 @@ __device__ __forceinline__ void resolve_moves(int lane, int P, bool is_pol, int 
         if (!occ && !((skipm >> k) & 1ull) && lane == k) {
             pos_v = tgt;
             mon_v -= cost_v;                                                // :234-236
+        }
+    }
+}
+
+// Same result as resolve_moves, with a parallel fast path: when no police target coincides with
+// another police officer's current node or target, the sequential order cannot matter and every
+// non-skipped officer whose target differs from its own node simply moves.  P independent ballots
+// instead of a chain of P dependent ones; conflicts (rare on a sparse board) take the exact loop.
+template <int PT>
+__device__ __forceinline__ void resolve_moves_fast(int lane, int P, bool is_pol, int tgt_v, uint64_t skipm, int cost_v,
+                                                   int& pos_v, int& mon_v) {
+    const int t0 = rdlane(tgt_v, 0);
+    const bool blocked = __ballot(is_pol && pos_v == t0) != 0ull;            // MrX vs PRE-move police (:180-188)
+    uint64_t conf = 0ull;
+#pragma unroll
+    for (int k = 1; k < SY_MAX_AGENTS; ++k) {
+        if (k <= P) {
+            const int tk = rdlane(tgt_v, k);
+            conf |= __ballot(is_pol && lane != k && (pos_v == tk || tgt_v == tk));
+        }
+    }
+    if (!blocked && lane == 0) pos_v = t0;
+    if (conf == 0ull) {
+        if (is_pol && !((skipm >> lane) & 1ull) && tgt_v != pos_v) {
+            pos_v = tgt_v;
+            mon_v -= cost_v;                                                  // :234-236
+        }
+    } else {
+        for (int k = 1; k <= P; ++k) {
+            const int tgt = rdlane(tgt_v, k);
+            const bool occ = __ballot(is_pol && pos_v == tgt) != 0ull;        // own node included (:231)
+            if (!occ && !((skipm >> k) & 1ull) && lane == k) {
+                pos_v = tgt;
+                mon_v -= cost_v;
+            }
         }
     }
 }
@@ -758,11 +841,16 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
     for (int i = lane; i < (NS >> 3); i += kWave)
         reinterpret_cast<uint4*>(E.vis_s)[i] = reinterpret_cast<const uint4*>(p.st.visits + (size_t)e * NS)[i];
     int rev_ctr = p.reveal_k > 0 ? p.reveal_k - (t % p.reveal_k) : 0;   // steps until the next reveal
-    uint32_t aff;
-    int qcnt;
-    scan_masks(L.ell_s, E.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, aff, qcnt);  // pre-step masks
-    uint32_t xw[4];   // action draws of 4 consecutive steps: word (step_count & 3) of philox(env, step_count >> 2, ACT, lane)
+    // action draws: word (step_count & 3) of philox(env, step_count >> 2, ACT, lane) serves the step with that
+    // counter; the action of the NEXT step is sampled inside each scan, so xw always covers the next counter.
+    uint32_t xw[4];
     philox4(gid, sc >> 2, kPurposeAct, (uint32_t)lane, p.seed_lo, p.seed_hi, xw);
+    auto draw_word = [&xw](uint32_t c) {
+        const uint32_t m = c & 3u;
+        return m == 0 ? xw[0] : (m == 1 ? xw[1] : (m == 2 ? xw[2] : xw[3]));
+    };
+    int qcnt, act_v, cost_v;
+    scan_sample(L.ell_s, E.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, draw_word(sc), act_v, cost_v, qcnt);
 
     // trajectory cursors: uniform base pointers advanced once per step + constant 32-bit lane offsets.
     // The per-step record (reward, pos, budget, action, t, flags) is assembled in LDS in its packed
@@ -778,22 +866,10 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
     int term = 0, trunc = 0, win = 0;
 
     for (int s = 0; s < T; ++s) {
-        // ---- A. uniform over the agent's valid mask, -1 when it is empty (random_agent.py)
-        const int k = __popc(aff);
-        const uint32_t m = sc & 3u;
-        const uint32_t x = m == 0 ? xw[0] : (m == 1 ? xw[1] : (m == 2 ? xw[2] : xw[3]));
-        const int r = (int)__umulhi(x, (uint32_t)k);
-        uint32_t f = aff;
-        for (int i = 0; i < r; ++i) f &= f - 1;
-        const int bit = f ? __ffs((int)f) - 1 : 0;
-        const uint32_t ent = L.ell_s[(pos_v << 4) | bit];
-        const bool ok_v = (lane < A) && (k > 0);
-        const int act_v = ok_v ? (int)(ent & 0xffffu) : -1;
-        const int cost_v = ok_v ? (int)(ent >> 16) : 0;
-        // ---- C. moves (yard.py:161-243)
+        // ---- C. moves (yard.py:161-243); this step's action was sampled by the previous scan
         const int pos0_v = pos_v, mon0_v = mon_v;   // pre-step observation, recorded below
         const uint64_t skipm = __ballot(act_v == -1 || mon_v == 0);               // :210-215
-        resolve_moves(lane, P, is_pol, act_v >= 0 ? act_v : pos_v, skipm, cost_v, pos_v, mon_v);
+        resolve_moves_fast<PT>(lane, P, is_pol, act_v >= 0 ? act_v : pos_v, skipm, cost_v, pos_v, mon_v);
         const uint64_t polm = ((1ull << P) - 1ull) << 1;
         const bool no_money = (skipm & polm) == polm;                             // :191,216
         // node_visit_counts (yard.py:244-245): police never share a node, so no conflicts
@@ -827,8 +903,12 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
             }
         }
 
-        // ---- F. post-move scan: masks for the next observation + position-reward counts
-        scan_masks(L.ell_s, E.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, aff, qcnt);
+        // ---- F. post-move scan: masks for the next observation, position-reward counts, next action
+        const uint32_t nxt = sc + 1u;
+        if ((nxt & 3u) == 0u) philox4(gid, nxt >> 2, kPurposeAct, (uint32_t)lane, p.seed_lo, p.seed_hi, xw);
+        const uint32_t x_next = draw_word(nxt);
+        int act_n, cost_n;
+        scan_sample(L.ell_s, E.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, x_next, act_n, cost_n, qcnt);
 
         // ---- D. outcome priority (reward_calculator.py:63-90), flags shared by all agents
         const bool captured = __ballot(is_pol && pos_v == mrx) != 0ull;
@@ -841,7 +921,6 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
         else rew = shaped_reward<true>(tb, lane, P, is_pol, t, qcnt, vc, dm, dj, kc);
         t += 1;   // yard.py:355
         sc += 1;
-        if ((sc & 3u) == 0u) philox4(gid, sc >> 2, kPurposeAct, (uint32_t)lane, p.seed_lo, p.seed_hi, xw);
         if (REC) {
             if (lane < A) {
                 rec_rew[0] = __double2loint(rew);
@@ -867,7 +946,7 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
             rev_ctr = p.reveal_k;
             for (int i = lane; i < (NS >> 3); i += kWave) reinterpret_cast<uint4*>(E.vis_s)[i] = make_uint4(0, 0, 0, 0);
             wave_lds_fence();
-            scan_masks(L.ell_s, E.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, aff, qcnt);
+            scan_sample(L.ell_s, E.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, x_next, act_n, cost_n, qcnt);
             flags = 1;
         } else if (p.reveal_k > 0 && --rev_ctr == 0) {   // post-increment timestep is a multiple of reveal_k
             rev_ctr = p.reveal_k;
@@ -881,6 +960,8 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
             asm volatile("" ::: "memory");
             if (lane == 0) lds_poke(E.sync, s + 1);
         }
+        act_v = act_n;
+        cost_v = cost_n;
     }
 
     // ---- write the live state back (coalesced); state pointers re-read from the kernel arguments

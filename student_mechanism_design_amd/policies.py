@@ -1,0 +1,137 @@
+"""Batched PyTorch-ROCm policies for the collector: the policy forward stays
+in PyTorch, only the env is a HIP engine.
+
+* `MappoPolicy` — the networks of `src/agent/mappo_agent.py:6-44` (per-agent 2-layer MLP actors with a
+  softmax head, one central 2-layer MLP critic), evaluated for all B envs at once.  Observations follow
+  the trainer (`mappo_trainer.py:173,197`): MrX sees one-hot(MrX_pos), every police sees the multi-hot
+  of all police positions; the critic sees their concatenation.
+* `AntiSymmetricConvDense` / `GnnQPolicy` — pure-torch restatement of the model in
+  `src/agent/gnn_agent.py:230-257` (2 x torch_geometric `AntiSymmetricConv` + Linear -> per-node Q).
+  torch_geometric is absent offline: **parity unpinned**; the layer follows the published form
+  x + eps * tanh((W - W^T - gamma I) x + GCN(x) + b) (Gravina et al., ICLR 2023) with PyG's defaults
+  (phi = GCNConv(in, in, bias=False), num_iters = 1).
+* `ppo_loss` — the clipped surrogate / critic MSE of `MappoAgent.ppo_update` (mappo_agent.py:260-293).
+"""
+from typing import Dict, Optional
+
+import torch
+import torch.nn as nn
+
+from .collector import masked_categorical_sample
+
+
+def one_hot_nodes(pos: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """pos int[B] or int[B, K] -> float[B, N] (multi-hot over K)."""
+    if pos.dim() == 1:
+        pos = pos.unsqueeze(-1)
+    out = torch.zeros((pos.shape[0], num_nodes), dtype=torch.float32, device=pos.device)
+    out.scatter_(1, pos.long(), 1.0)
+    return out
+
+
+class MappoPolicy(nn.Module):
+    def __init__(self, num_nodes: int, num_police: int, hidden_size: int = 64):
+        super().__init__()
+        self.N, self.P, self.A = num_nodes, num_police, num_police + 1
+
+        def actor():
+            return nn.Sequential(nn.Linear(num_nodes, hidden_size), nn.ReLU(), nn.Linear(hidden_size, num_nodes))
+
+        self.actors = nn.ModuleList([actor() for _ in range(self.A)])       # AgentPolicy, mappo_agent.py:6-29
+        self.critic = nn.Sequential(nn.Linear(num_nodes * self.A, hidden_size), nn.ReLU(),
+                                    nn.Linear(hidden_size, 1))              # CentralCritic, :32-44
+
+    def observations(self, obs: Dict[str, torch.Tensor]):
+        mrx = one_hot_nodes(obs["MrX_pos"], self.N)
+        pol = one_hot_nodes(obs["Polices_pos"], self.N)
+        return mrx, pol
+
+    def probs(self, obs: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """[B, A, N] action probabilities before masking."""
+        mrx, pol = self.observations(obs)
+        out = [torch.softmax(self.actors[0](mrx), -1)]
+        out += [torch.softmax(self.actors[k](pol), -1) for k in range(1, self.A)]
+        return torch.stack(out, dim=1)
+
+    def value(self, obs: Dict[str, torch.Tensor]) -> torch.Tensor:
+        mrx, pol = self.observations(obs)
+        g = torch.cat([mrx] + [pol] * self.P, dim=-1)
+        return self.critic(g).squeeze(-1)
+
+    @torch.no_grad()
+    def act(self, obs: Dict[str, torch.Tensor], generator: Optional[torch.Generator] = None):
+        """Collector callback: masked sampling as in MappoAgent.select_action (mappo_agent.py:87-142)."""
+        mask = obs["action_mask"]
+        a, logp, _ = masked_categorical_sample(self.probs(obs), mask, generator=generator)
+        a = torch.where(mask.sum(-1) == 0, torch.full_like(a, -1), a)   # nothing legal -> DEFAULT_ACTION
+        return a.to(torch.int32), logp.float(), self.value(obs)
+
+
+class AntiSymmetricConvDense(nn.Module):
+    def __init__(self, channels: int, epsilon: float = 0.1, gamma: float = 0.1):
+        super().__init__()
+        self.W = nn.Parameter(torch.empty(channels, channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+        self.phi = nn.Linear(channels, channels, bias=False)     # GCNConv weight
+        self.epsilon, self.gamma = epsilon, gamma
+        nn.init.kaiming_uniform_(self.W, a=5 ** 0.5)
+
+    def forward(self, x: torch.Tensor, a_hat: torch.Tensor) -> torch.Tensor:
+        """x [B, N, F]; a_hat [B or 1, N, N] = D^-1/2 (A + I) D^-1/2."""
+        eye = torch.eye(self.W.shape[0], device=x.device, dtype=x.dtype)
+        anti = self.W - self.W.t() - self.gamma * eye
+        h = x @ anti.t() + a_hat @ self.phi(x) + self.bias
+        return x + self.epsilon * torch.tanh(h)
+
+
+def normalized_adjacency(ell: torch.Tensor, num_nodes: int) -> torch.Tensor:
+    """Dense GCN propagation matrix per board from the packed ELL table int32/uint32 [G, N, 16]."""
+    G = ell.shape[0]
+    nb = (ell.long() & 0xFFFF)
+    adj = torch.zeros((G, num_nodes, num_nodes + 1), dtype=torch.float32, device=ell.device)
+    adj.scatter_(2, nb.clamp_max(num_nodes), 1.0)
+    adj = adj[..., :num_nodes] + torch.eye(num_nodes, device=ell.device)
+    d = adj.sum(-1).rsqrt()
+    return d.unsqueeze(-1) * adj * d.unsqueeze(-2)
+
+
+class GnnQPolicy(nn.Module):
+    """Per-node Q values (gnn_agent.py:230-257) over node features [one-hot positions of all agents | belief]."""
+
+    def __init__(self, num_agents: int, with_belief: bool = True):
+        super().__init__()
+        f = num_agents + (1 if with_belief else 0)
+        self.with_belief = with_belief
+        self.conv1 = AntiSymmetricConvDense(f)
+        self.conv2 = AntiSymmetricConvDense(f)
+        self.out = nn.Linear(f, 1)
+
+    def features(self, obs: Dict[str, torch.Tensor], num_nodes: int) -> torch.Tensor:
+        pos = obs["agent_position"].long()                                  # [B, A]
+        x = torch.zeros((pos.shape[0], num_nodes, pos.shape[1]), device=pos.device)
+        x.scatter_(1, pos.unsqueeze(1), 1.0)                                # node_features, yard.py:279-290
+        if self.with_belief and obs.get("belief_map") is not None:
+            x = torch.cat([x, obs["belief_map"].unsqueeze(-1)], dim=-1)
+        return x
+
+    def forward(self, x: torch.Tensor, a_hat: torch.Tensor) -> torch.Tensor:
+        x = torch.relu(self.conv1(x, a_hat))
+        x = torch.relu(self.conv2(x, a_hat))
+        return self.out(x).squeeze(-1)                                       # [B, N]
+
+    @torch.no_grad()
+    def act_greedy(self, obs: Dict[str, torch.Tensor], a_hat: torch.Tensor):
+        """Masked arg-max per agent (evaluator.py greedy loop); every agent shares the Q map here."""
+        mask = obs["action_mask"]
+        q = self.forward(self.features(obs, mask.shape[-1]), a_hat).unsqueeze(1).expand_as(mask)
+        q = q.masked_fill(~mask, float("-inf"))
+        a = q.argmax(-1)
+        a = torch.where(mask.sum(-1) == 0, torch.full_like(a, -1), a)
+        return a.to(torch.int32), None, None
+
+
+def ppo_loss(new_log_prob, old_log_prob, advantages, values, returns, clip: float = 0.2):
+    """mappo_agent.py:260-293: critic MSE + clipped surrogate (no entropy / value coefficients)."""
+    ratio = torch.exp(new_log_prob - old_log_prob)
+    surr = torch.min(ratio * advantages, torch.clamp(ratio, 1 - clip, 1 + clip) * advantages)
+    return -surr.mean(), torch.nn.functional.mse_loss(values, returns)

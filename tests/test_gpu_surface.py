@@ -138,3 +138,49 @@ def test_policy_driven_collector_matches_fused_rollout(sy):
     torch.testing.assert_close(ret, ret2)
     for e in (a, b, c):
         e.close()
+
+
+def test_config3_policy_collect_and_ppo_update_on_device(sy):
+    """BASELINE configs[2] in miniature: torch policy forward on the GPU, rollout kept on device,
+    returns/GAE and one clipped-PPO update without leaving the device."""
+    from student_mechanism_design_amd import collector as col, policies as pol
+    N, P, B, T = 200, 4, 256, 16
+    boards = sy.sample_board_pool(2, N, 400, seed=0)
+    env = sy.BatchedScotlandYardEnv(B, boards, P, 20, np.full(11, 0.5), seed=2, reveal_interval=5)
+    net = pol.MappoPolicy(N, P, hidden_size=64).to(env.device)
+    gen = torch.Generator(device=env.device).manual_seed(0)
+    rec = col.RolloutCollector(env, lambda obs: net.act(obs, generator=gen), frames_per_batch=T).collect()
+    assert rec["action"].device.type == "cuda" and rec["value"].shape == (T, B)
+    act, mask = rec["action"].long(), rec["mask"][..., :N].bool()
+    legal = torch.gather(mask, -1, act.clamp_min(0).unsqueeze(-1)).squeeze(-1)
+    assert bool((legal | (act < 0)).all())
+    done = (rec["terminated"] | rec["truncated"]).bool()
+    team_reward = rec["reward"].float()
+    ret = col.discounted_returns(team_reward, done, 0.99)                     # mappo_agent.py:247-254
+    adv, ret_gae = col.gae(team_reward.sum(-1), rec["value"], done, torch.zeros(B, device=env.device), 0.99, 0.95)
+    assert torch.isfinite(ret).all() and torch.isfinite(adv).all()
+    # one PPO step over the flattened batch
+    opt = torch.optim.Adam(net.parameters(), lr=3e-4)
+    flat_obs = {"MrX_pos": rec["pos"][..., 0].reshape(-1), "Polices_pos": rec["pos"][..., 1:].reshape(-1, P)}
+    probs = net.probs(flat_obs).reshape(T, B, P + 1, N)
+    m = mask.float()
+    pm = probs * m
+    pm = pm / (pm.sum(-1, keepdim=True) + 1e-8)
+    new_lp = torch.log(torch.gather(pm, -1, act.clamp_min(0).unsqueeze(-1)).squeeze(-1) + 1e-8)
+    a_std = col.standardized_advantages(ret_gae, rec["value"]).unsqueeze(-1).expand_as(new_lp)
+    valid = (act >= 0).float()
+    al, cl = pol.ppo_loss(new_lp * valid, rec["log_prob"] * valid, a_std, net.value(flat_obs).reshape(T, B), ret_gae)
+    before = [p.detach().clone() for p in net.parameters()]
+    opt.zero_grad()
+    (al + cl).backward()
+    opt.step()
+    assert torch.isfinite(al) and torch.isfinite(cl)
+    assert any(not torch.equal(a, b) for a, b in zip(before, net.parameters()))
+    # the GNN Q-policy drives the same collector greedily
+    a_hat = pol.normalized_adjacency(env.ell, N)[env.env_graph.long()]
+    gnn = pol.GnnQPolicy(P + 1).to(env.device)
+    rec2 = col.RolloutCollector(env, lambda obs: gnn.act_greedy(obs, a_hat), frames_per_batch=4).collect()
+    act2 = rec2["action"].long()
+    legal2 = torch.gather(rec2["mask"][..., :N].bool(), -1, act2.clamp_min(0).unsqueeze(-1)).squeeze(-1)
+    assert bool((legal2 | (act2 < 0)).all())
+    env.close()

@@ -1,0 +1,75 @@
+"""CPU tests of the torch policies (device-agnostic code; the env side is covered by the GPU tests)."""
+import numpy as np
+import torch
+
+import student_mechanism_design_amd as sy
+from student_mechanism_design_amd import policies as pol
+
+
+def _fake_obs(B, N, P, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    pos = torch.stack([torch.randperm(N, generator=g)[: P + 1] for _ in range(B)]).int()
+    mask = torch.rand(B, P + 1, N, generator=g) < 0.05
+    mask[0, 1] = False   # an agent without legal moves
+    return {"MrX_pos": pos[:, 0], "Polices_pos": pos[:, 1:], "agent_position": pos, "action_mask": mask,
+            "belief_map": torch.full((B, N), 1.0 / N)}
+
+
+def test_mappo_policy_shapes_and_masking():
+    B, N, P = 32, 40, 3
+    obs = _fake_obs(B, N, P)
+    net = pol.MappoPolicy(N, P, hidden_size=16)
+    pr = net.probs(obs)
+    assert pr.shape == (B, P + 1, N)
+    torch.testing.assert_close(pr.sum(-1), torch.ones(B, P + 1))
+    a, logp, v = net.act(obs, generator=torch.Generator().manual_seed(1))
+    assert a.shape == (B, P + 1) and a.dtype == torch.int32 and logp.shape == (B, P + 1) and v.shape == (B,)
+    legal = torch.gather(obs["action_mask"], -1, a.clamp_min(0).long().unsqueeze(-1)).squeeze(-1)
+    assert bool((legal | (a < 0)).all()) and int(a[0, 1]) == -1
+    # observations as the reference trainer builds them (mappo_trainer.py:173,197)
+    mrx, police = net.observations(obs)
+    assert mrx.sum(-1).eq(1).all() and police.sum(-1).eq(P).all()
+    # one PPO step decreases nothing weird: losses finite, gradients flow to actors and critic
+    adv = torch.randn(B, P + 1)
+    newlp = torch.log(torch.gather(net.probs(obs), -1, a.clamp_min(0).long().unsqueeze(-1)).squeeze(-1) + 1e-8)
+    al, cl = pol.ppo_loss(newlp, logp, adv, net.value(obs), torch.randn(B))
+    (al + cl).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_antisymmetric_conv_matches_its_formula():
+    torch.manual_seed(0)
+    boards = sy.sample_board_pool(2, 12, 18, seed=1)
+    pool = sy.pack_pool(boards)
+    ell = torch.from_numpy(pool.ell.view(np.int32).copy())
+    a_hat = pol.normalized_adjacency(ell, 12)
+    # reference construction of D^-1/2 (A+I) D^-1/2
+    for gi, b in enumerate(boards):
+        A = np.zeros((12, 12))
+        A[b.edge_links[:, 0], b.edge_links[:, 1]] = 1
+        A[b.edge_links[:, 1], b.edge_links[:, 0]] = 1
+        A += np.eye(12)
+        d = A.sum(1) ** -0.5
+        np.testing.assert_allclose(a_hat[gi].numpy(), d[:, None] * A * d[None, :], rtol=1e-6)
+    conv = pol.AntiSymmetricConvDense(5)
+    x = torch.randn(3, 12, 5)
+    y = conv(x, a_hat[:1])
+    W = conv.W.detach()
+    ref = x + 0.1 * torch.tanh(x @ (W - W.t() - 0.1 * torch.eye(5)).t() + a_hat[:1] @ conv.phi(x) + conv.bias)
+    torch.testing.assert_close(y, ref)
+    # the weight matrix acting on x is anti-symmetric up to the -gamma*I damping (the layer's point)
+    M = W - W.t()
+    torch.testing.assert_close(M, -M.t())
+
+
+def test_gnn_q_policy_greedy_respects_mask():
+    B, N, P = 16, 12, 2
+    obs = _fake_obs(B, N, P, seed=3)
+    boards = sy.sample_board_pool(1, N, 18, seed=1)
+    a_hat = pol.normalized_adjacency(torch.from_numpy(sy.pack_pool(boards).ell.view(np.int32).copy()), N)
+    net = pol.GnnQPolicy(P + 1, with_belief=True)
+    x = net.features(obs, N)
+    assert x.shape == (B, N, P + 2) and x[..., : P + 1].sum() == B * (P + 1)
+    a, _, _ = net.act_greedy(obs, a_hat)
+    legal = torch.gather(obs["action_mask"], -1, a.clamp_min(0).long().unsqueeze(-1)).squeeze(-1)
+    assert bool((legal | (a < 0)).all())

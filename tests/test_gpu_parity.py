@@ -152,6 +152,13 @@ def test_step_matches_oracle(sy, ol, cfg):
     dict(B=33, N=15, E=20, P=2, money=10, G=1, seed=12, T=300),
     dict(B=40, N=100, E=190, P=6, money=6, G=2, seed=13, police_evidence=True, reveal_interval=4, T=80),
     dict(B=24, N=40, E=70, P=3, money=50, G=1, seed=14, max_timestep=30, T=200),
+    # BASELINE configs[3] shape on one rank's shard: 6 police, global env ids of rank 3 of 8
+    dict(B=96, N=200, E=400, P=6, money=20, G=2, seed=15, reveal_interval=5, env_id_offset=3 * 4096, T=48),
+    # BASELINE configs[4] stand-in: 199 nodes (no London topology offline), 5 police, reveal every 5
+    dict(B=72, N=199, E=380, P=5, money=24, G=3, seed=16, reveal_interval=5, T=64),
+    # odd block sizes / partial blocks: 7 envs per block, 3 belief waves + a half-used one
+    dict(B=45, N=70, E=120, P=4, money=9, G=1, seed=17, reveal_interval=2, police_evidence=True, waves_per_block=7, T=40),
+    dict(B=9, N=520, E=1000, P=2, money=6, G=1, seed=18, reveal_interval=6, waves_per_block=2, T=30),
 ])
 def test_fused_rollout_matches_oracle(sy, ol, cfg):
     cfg = dict(cfg)

@@ -94,14 +94,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("SY_BENCH_BACKEND", "nccl")   # "gloo" only to rehearse the N>1 path on a 1-GPU box
+    ndev = max(torch.cuda.device_count(), 1)
+    dev_index = local_rank % ndev if world > 1 else 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        torch.cuda.set_device(dev_index)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend=backend)
     elif args.gpus > 1:
         print("launch with torch.distributed.run for --gpus > 1", file=sys.stderr)
         sys.exit(2)
-    device = torch.device("cuda", local_rank if world > 1 else 0)
+    device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
 
     N, P, A, B, T = args.nodes, args.police, args.police + 1, args.envs, args.fused
@@ -134,7 +140,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 

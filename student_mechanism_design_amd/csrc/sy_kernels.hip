@@ -859,6 +859,7 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
     const uint32_t off_rec = ((uint32_t)e * (uint32_t)RW + (uint32_t)lane) * 4u;
     const uint32_t off_mask = (uint32_t)e * (uint32_t)(A * NS) + (uint32_t)lane * 16u;
     const size_t BA = (size_t)B * A;
+    E.rec_s[lane] = 0;                            // padding words of the record row stay zero
     int* rec_rew = E.rec_s + 2 * lane;            // lane a: reward as two dwords
     int* rec_pos = E.rec_s + 2 * A + lane;        // lane a: pos / budget / action at +0, +A, +2A
 

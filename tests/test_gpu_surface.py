@@ -184,3 +184,35 @@ def test_config3_policy_collect_and_ppo_update_on_device(sy):
     legal2 = torch.gather(rec2["mask"][..., :N].bool(), -1, act2.clamp_min(0).unsqueeze(-1)).squeeze(-1)
     assert bool((legal2 | (act2 < 0)).all())
     env.close()
+
+
+def test_step_and_rollout_are_hip_graph_capturable(sy):
+    """The ABI promises: no allocation, no sync, everything on the caller's stream -> the calls can be
+    captured into a HIP graph (torch.cuda.CUDAGraph) and replayed."""
+    boards = sy.sample_board_pool(1, 50, 90, seed=6)
+    w = np.linspace(0.1, 0.9, 11)
+    eager = sy.BatchedScotlandYardEnv(128, boards, 4, 15, w, seed=4, reveal_interval=5)
+    graphed = sy.BatchedScotlandYardEnv(128, boards, 4, 15, w, seed=4, reveal_interval=5)
+    rec = eager.alloc_rollout(6)
+    rec_g = graphed.alloc_rollout(6)
+    act = torch.full((128, 5), -1, dtype=torch.int32, device=eager.device)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            graphed.rollout(6, out=rec_g)
+            graphed.step(act)
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(3):      # replay == the same calls issued eagerly
+        g.replay()
+        eager.rollout(6, out=rec)
+        eager.step(act)
+    torch.cuda.synchronize()
+    bad = [name for name in ("pos", "budget", "t", "step_count", "_mask", "_belief", "_visits", "reward", "_terminated")
+           if not torch.equal(getattr(eager, name), getattr(graphed, name))]
+    assert not bad, (bad, eager.step_count[:4].tolist(), graphed.step_count[:4].tolist())
+    assert torch.equal(rec["record"], rec_g["record"]) and torch.equal(rec["belief"], rec_g["belief"])
+    eager.close()
+    graphed.close()

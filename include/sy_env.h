@@ -149,6 +149,10 @@ int sy_belief_update(const uint32_t *ell, const float *inv_deg, int32_t num_node
                      float *belief, const int32_t *hint, int32_t hint_width, const int32_t *reveal,
                      int32_t num_queries, void *stream);
 
+/* replaces Pathfinder.get_distance (pathfinding.py:34-137) for a whole pool: all-pairs weighted
+ * shortest paths from the ELL table, apsp uint16 [G][N][N] (0xFFFF = unreachable); all device */
+int sy_build_apsp(const uint32_t *ell, int32_t num_nodes, int32_t num_graphs, uint16_t *apsp, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

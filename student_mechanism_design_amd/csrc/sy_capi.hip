@@ -221,4 +221,12 @@ int sy_belief_update(const uint32_t* ell, const float* inv_deg, int32_t num_node
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_belief_update launch");
 }
 
+int sy_build_apsp(const uint32_t* ell, int32_t num_nodes, int32_t num_graphs, uint16_t* apsp, void* stream) {
+    if (!ell || !apsp) return fail(SY_ERR_INVALID, "sy_build_apsp: null argument%s");
+    if (num_nodes < 1 || num_nodes > SY_MAX_NODES || num_graphs < 1) return fail(SY_ERR_INVALID, "sy_build_apsp: bad sizes%s");
+    if ((reinterpret_cast<uintptr_t>(ell) & 15)) return fail(SY_ERR_INVALID, "ell must be 16-byte aligned%s");
+    hipError_t e = sy::launch_apsp(ell, num_nodes, num_graphs, apsp, (hipStream_t)stream);
+    return e == hipSuccess ? SY_OK : hip_fail(e, "sy_build_apsp launch");
+}
+
 }  // extern "C"

@@ -41,4 +41,6 @@ hipError_t launch_action_mask_dense(const double* adj, const double* wts, const 
 hipError_t launch_belief_update(const uint32_t* ell, const float* inv_deg, int N, int NS, float* belief, const int32_t* hint,
                                 int H, const int32_t* reveal, int Q, hipStream_t stream);
 
+hipError_t launch_apsp(const uint32_t* ell, int N, int G, uint16_t* apsp, hipStream_t stream);
+
 }  // namespace sy

@@ -1156,6 +1156,65 @@ __global__ __launch_bounds__(256) void belief_update_kernel(const uint32_t* __re
 }
 
 // ---------------------------------------------------------------------------------------------
+// All-pairs weighted shortest paths of a board pool (replaces per-query Dijkstra, pathfinding.py:34-137,
+// and the host Floyd-Warshall for large pools): one wave per (board, source) runs Bellman-Ford over
+// the ELL rows with the distance vector in LDS; integer weights -> exact.  Unreachable = 0xFFFF.
+// ---------------------------------------------------------------------------------------------
+template <int NR>
+__global__ __launch_bounds__(256) void apsp_kernel(const uint32_t* __restrict__ ell, int N, uint16_t* __restrict__ apsp) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
+    const int g = blockIdx.y;
+    uint32_t* ell_s = reinterpret_cast<uint32_t*>(smem);
+    int* dist_s = reinterpret_cast<int*>(smem + (size_t)N * kD * 4) + (size_t)wid * (N + 16);
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(ell + (size_t)g * N * kD);
+        uint4* dst = reinterpret_cast<uint4*>(ell_s);
+        for (int i = threadIdx.x; i < N * 4; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int source = blockIdx.x * wpb + wid;
+    if (source >= N) return;
+    constexpr int kInf = 0x3fffffff;
+    int d[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) d[r] = (lane + 64 * r == source) ? 0 : kInf;
+    for (int it = 0; it < N; ++it) {          // at most N-1 relaxation rounds; stops when nothing changes
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (lane + 64 * r < N) dist_s[lane + 64 * r] = d[r];
+        if (lane == 0) dist_s[N] = kInf;      // padding entries point here
+        wave_lds_fence();
+        bool changed = false;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int j = lane + 64 * r;
+            const int jj = j < N ? j : N - 1;
+            const uint4* row = reinterpret_cast<const uint4*>(ell_s + (jj << 4));
+            int nd = d[r];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint4 v = row[q];
+                nd = min(nd, dist_s[v.x & 0xffffu] + (int)(v.x >> 16));
+                nd = min(nd, dist_s[v.y & 0xffffu] + (int)(v.y >> 16));
+                nd = min(nd, dist_s[v.z & 0xffffu] + (int)(v.z >> 16));
+                nd = min(nd, dist_s[v.w & 0xffffu] + (int)(v.w >> 16));
+            }
+            changed = changed || (j < N && nd < d[r]);
+            d[r] = nd;
+        }
+        wave_lds_fence();
+        if (__ballot(changed) == 0ull) break;
+    }
+    uint16_t* out = apsp + ((size_t)g * N + source) * N;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = lane + 64 * r;
+        if (j < N) out[j] = d[r] < 0xFFFF ? (uint16_t)d[r] : (uint16_t)0xFFFF;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launchers (called from the C ABI, sy_capi.hip)
 // ---------------------------------------------------------------------------------------------
 template <int NR>
@@ -1227,6 +1286,23 @@ hipError_t launch_belief_update(const uint32_t* ell, const float* inv_deg, int N
     if (nr <= 4) return launch_belief_nr<4>(ell, inv_deg, N, NS, belief, hint, H, reveal, Q, stream);
     if (nr <= 8) return launch_belief_nr<8>(ell, inv_deg, N, NS, belief, hint, H, reveal, Q, stream);
     return launch_belief_nr<16>(ell, inv_deg, N, NS, belief, hint, H, reveal, Q, stream);
+}
+
+template <int NR>
+static hipError_t launch_apsp_nr(const uint32_t* ell, int N, int G, uint16_t* apsp, hipStream_t stream) {
+    const int wpb = 4;
+    const size_t lds = (size_t)N * kD * 4 + (size_t)wpb * (N + 16) * 4;
+    hipLaunchKernelGGL((apsp_kernel<NR>), dim3((N + wpb - 1) / wpb, G), dim3(wpb * 64), lds, stream, ell, N, apsp);
+    return hipGetLastError();
+}
+
+hipError_t launch_apsp(const uint32_t* ell, int N, int G, uint16_t* apsp, hipStream_t stream) {
+    const int nr = (N + 63) / 64;
+    if (nr <= 1) return launch_apsp_nr<1>(ell, N, G, apsp, stream);
+    if (nr <= 2) return launch_apsp_nr<2>(ell, N, G, apsp, stream);
+    if (nr <= 4) return launch_apsp_nr<4>(ell, N, G, apsp, stream);
+    if (nr <= 8) return launch_apsp_nr<8>(ell, N, G, apsp, stream);
+    return launch_apsp_nr<16>(ell, N, G, apsp, stream);
 }
 
 }  // namespace sy

@@ -184,6 +184,26 @@ class PackedPool:
     inv_deg: np.ndarray  # float32 [G][NS]
 
 
+def device_all_pairs_shortest_paths(ell, num_nodes: int, device="cuda"):
+    """APSP of a whole pool on the GPU (`sy_build_apsp`): ell uint32 [G, N, 16] (numpy or int32 torch
+    tensor) -> uint16-valued torch int16 tensor [G, N, N] on `device`.  No CPU fallback."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    if not torch.cuda.is_available():
+        raise _lib.EngineError("device_all_pairs_shortest_paths needs a GPU; use all_pairs_shortest_paths on the host")
+    dev = torch.device(device)
+    ell_t = ell if isinstance(ell, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(ell).view(np.int32).copy())
+    ell_t = ell_t.to(dev).contiguous()
+    G = ell_t.shape[0]
+    out = torch.empty((G, num_nodes, num_nodes), dtype=torch.int16, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.sy_build_apsp(C.c_void_p(ell_t.data_ptr()), int(num_nodes), int(G), C.c_void_p(out.data_ptr()), stream),
+               "sy_build_apsp")
+    return out
+
+
 def pack_pool(boards: Sequence[Board], node_stride: Optional[int] = None) -> PackedPool:
     boards = list(boards)
     n = boards[0].num_nodes

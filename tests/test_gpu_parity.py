@@ -320,3 +320,24 @@ def test_errors_are_reported_not_thrown_across_the_abi(sy):
     assert lib.sy_env_destroy(h) == 0
     with pytest.raises(ValueError):
         sy.BatchedScotlandYardEnv(4, [sy.sample_board(10, 14, rng=np.random.default_rng(0))], 2, 10, np.zeros(5))
+
+
+def test_device_apsp_matches_host_and_reference_distances(sy):
+    """sy_build_apsp (Bellman-Ford per source on the GPU) == host Floyd-Warshall == the reference's
+    Dijkstra distances (they feed the golden float64 rewards) — bit-exact integers."""
+    boards = sy.sample_board_pool(5, 200, 400, seed=9) 
+    pool = sy.pack_pool(boards)
+    dev = sy.device_all_pairs_shortest_paths(pool.ell, 200)
+    np.testing.assert_array_equal(_np(dev).view(np.uint16), pool.apsp)
+    for n, e, seed in ((15, 20, 1), (64, 63, 2), (130, 250, 3), (520, 1000, 4)):
+        bs = sy.sample_board_pool(2, n, e, seed=seed)
+        pk = sy.pack_pool(bs)
+        np.testing.assert_array_equal(_np(sy.device_all_pairs_shortest_paths(pk.ell, n)).view(np.uint16), pk.apsp)
+    # golden board (N=200 reference trace) and a disconnected board (0xFFFF = unreachable)
+    tr = load_trace("trace_s10_n200_p4_m20_random_valid_ep0.npz")
+    b = sy.make_board(200, tr["edge_links"], tr["edge_w"])
+    np.testing.assert_array_equal(_np(sy.device_all_pairs_shortest_paths(sy.pack_ell(b)[None], 200))[0].view(np.uint16),
+                                  sy.all_pairs_shortest_paths(b))
+    two = sy.make_board(6, [[0, 1], [1, 2], [3, 4]], [2, 3, 1])
+    d = _np(sy.device_all_pairs_shortest_paths(sy.pack_ell(two)[None], 6))[0].view(np.uint16)
+    assert d[0, 2] == 5 and d[3, 4] == 1 and d[0, 3] == 0xFFFF and d[5, 0] == 0xFFFF and d[5, 5] == 0

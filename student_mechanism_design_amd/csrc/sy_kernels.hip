@@ -824,7 +824,6 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
     // ================================== move wave ==================================
     const uint16_t* __restrict__ ap = p.apsp + (size_t)g * N * N;
     const uint64_t gid = p.env_id_offset + (uint64_t)e;
-    const bool is_pol = lane >= 1 && lane <= P;
     const int n16 = (A * NS) >> 4;
     const ScanMap sm = make_scan_map(lane, p.scan_w);
     Coefs<true> kc;
@@ -867,10 +866,15 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
     int term = 0, trunc = 0, win = 0;
 
     for (int s = 0; s < T; ++s) {
+        // Lane predicates are recomputed from this laundered copy every step: hoisted out of the loop
+        // they would each pin an SGPR pair (and get spilled / reloaded by v_readlane).
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
+        const bool is_pol = ln >= 1 && ln <= P;
         // ---- C. moves (yard.py:161-243); this step's action was sampled by the previous scan
         const int pos0_v = pos_v, mon0_v = mon_v;   // pre-step observation, recorded below
         const uint64_t skipm = __ballot(act_v == -1 || mon_v == 0);               // :210-215
-        resolve_moves_fast<PT>(lane, P, is_pol, act_v >= 0 ? act_v : pos_v, skipm, cost_v, pos_v, mon_v);
+        resolve_moves_fast<PT>(ln, P, is_pol, act_v >= 0 ? act_v : pos_v, skipm, cost_v, pos_v, mon_v);
         const uint64_t polm = ((1ull << P) - 1ull) << 1;
         const bool no_money = (skipm & polm) == polm;                             // :191,216
         // node_visit_counts (yard.py:244-245): police never share a node, so no conflicts
@@ -898,18 +902,18 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
         if (REC) {
             if (out.mask) {
                 for (int base16 = 0; base16 < n16; base16 += kWave)   // wave-uniform trip count
-                    if (base16 + lane < n16)
+                    if (base16 + ln < n16)
                         *reinterpret_cast<uint4*>(out.mask + off_mask + (uint32_t)base16 * 16u) =
-                            reinterpret_cast<const uint4*>(E.mrow)[base16 + lane];
+                            reinterpret_cast<const uint4*>(E.mrow)[base16 + ln];
             }
         }
 
         // ---- F. post-move scan: masks for the next observation, position-reward counts, next action
         const uint32_t nxt = sc + 1u;
-        if ((nxt & 3u) == 0u) philox4(gid, nxt >> 2, kPurposeAct, (uint32_t)lane, p.seed_lo, p.seed_hi, xw);
+        if ((nxt & 3u) == 0u) philox4(gid, nxt >> 2, kPurposeAct, (uint32_t)ln, p.seed_lo, p.seed_hi, xw);
         const uint32_t x_next = draw_word(nxt);
         int act_n, cost_n;
-        scan_sample(L.ell_s, E.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, x_next, act_n, cost_n, qcnt);
+        scan_sample(L.ell_s, E.mrow, ln, A, NS, n16, p.scan_w, sm, pos_v, mon_v, x_next, act_n, cost_n, qcnt);
 
         // ---- D. outcome priority (reward_calculator.py:63-90), flags shared by all agents
         const bool captured = __ballot(is_pol && pos_v == mrx) != 0ull;
@@ -918,21 +922,21 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
         trunc = (!captured && timeout) ? 1 : 0;
         win = captured ? 1 : ((timeout || no_money) ? 2 : 0);
         const bool ended = (term | trunc) != 0;
-        if (ended) rew = captured ? (lane == 0 ? -1.0 : 1.0) : (lane == 0 ? 1.0 : 0.0);
-        else rew = shaped_reward<true>(tb, lane, P, is_pol, t, qcnt, vc, dm, dj, kc);
+        if (ended) rew = captured ? (ln == 0 ? -1.0 : 1.0) : (ln == 0 ? 1.0 : 0.0);
+        else rew = shaped_reward<true>(tb, ln, P, is_pol, t, qcnt, vc, dm, dj, kc);
         t += 1;   // yard.py:355
         sc += 1;
         if (REC) {
-            if (lane < A) {
+            if (ln < A) {
                 rec_rew[0] = __double2loint(rew);
                 rec_rew[1] = __double2hiint(rew);
                 rec_pos[0] = pos0_v;
                 rec_pos[A] = mon0_v;
                 rec_pos[2 * A] = act_v;
             }
-            if (lane < 4) E.rec_s[5 * A + lane] = lane == 0 ? t - 1 : (lane == 1 ? term : (lane == 2 ? trunc : win));
+            if (ln < 4) E.rec_s[5 * A + ln] = ln == 0 ? t - 1 : (ln == 1 ? term : (ln == 2 ? trunc : win));
             wave_lds_fence();
-            if (lane < RW) *at_bytes(out.record, off_rec) = E.rec_s[lane];
+            if (ln < RW) *at_bytes(out.record, off_rec) = E.rec_s[ln];
             out.record += (size_t)B * RW;
             if (out.mask) out.mask += BA * NS;
         }
@@ -940,14 +944,14 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
         // ---- E. next episode (auto-reset) and the hand-off to the belief wave
         int flags = 0;
         if (ended && p.auto_reset) {
-            const int st = sample_starts(lane, A, N, gid, sc, p.seed_lo, p.seed_hi);
-            pos_v = lane < A ? st : 0;
-            mon_v = lane == 0 ? SY_MRX_MONEY : (lane < A ? p.money0 : 0);   // yard.py:117-119
+            const int st = sample_starts(ln, A, N, gid, sc, p.seed_lo, p.seed_hi);
+            pos_v = ln < A ? st : 0;
+            mon_v = ln == 0 ? SY_MRX_MONEY : (ln < A ? p.money0 : 0);   // yard.py:117-119
             t = 0;
             rev_ctr = p.reveal_k;
-            for (int i = lane; i < (NS >> 3); i += kWave) reinterpret_cast<uint4*>(E.vis_s)[i] = make_uint4(0, 0, 0, 0);
+            for (int i = ln; i < (NS >> 3); i += kWave) reinterpret_cast<uint4*>(E.vis_s)[i] = make_uint4(0, 0, 0, 0);
             wave_lds_fence();
-            scan_sample(L.ell_s, E.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, x_next, act_n, cost_n, qcnt);
+            scan_sample(L.ell_s, E.mrow, ln, A, NS, n16, p.scan_w, sm, pos_v, mon_v, x_next, act_n, cost_n, qcnt);
             flags = 1;
         } else if (p.reveal_k > 0 && --rev_ctr == 0) {   // post-increment timestep is a multiple of reveal_k
             rev_ctr = p.reveal_k;
@@ -957,9 +961,9 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
             for (int spin = 0; s - lds_peek(E.sync + 1) >= kRing && spin < kSpinMax; ++spin) __builtin_amdgcn_s_sleep(2);
             asm volatile("" ::: "memory");
             int* slot_p = E.ring + (s & (kRing - 1)) * 8;
-            if (lane < 8) slot_p[lane] = lane == 0 ? (pos_v | (flags << 16)) : (lane <= P ? pos_v : -1);
+            if (ln < 8) slot_p[ln] = ln == 0 ? (pos_v | (flags << 16)) : (ln <= P ? pos_v : -1);
             asm volatile("" ::: "memory");
-            if (lane == 0) lds_poke(E.sync, s + 1);
+            if (ln == 0) lds_poke(E.sync, s + 1);
         }
         act_v = act_n;
         cost_v = cost_n;

@@ -37,12 +37,34 @@ def algorithmic_bytes_per_env_step(N, P):
     return R, W
 
 
+def usable_cores():
+    """Host cores this process may really use: the cgroup CPU quota when one is set (a 1-GPU box gets a
+    share of the host), else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as f:
+                txt = f.read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(np.ceil(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f2:
+                        n = min(n, max(1, int(np.ceil(q / int(f2.read())))))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(args, boards, weights, A):
     """The CPU oracle (plain-C port of the reference algorithm, OpenMP over envs) on a bounded sample
     of the same workload: the same boards / sizes, T_cpu fused steps of B envs."""
     from oracle import oracle_lib as ol
     import student_mechanism_design_amd as sy
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = usable_cores()
     graphs = [ol.OracleGraph(args.nodes, b.edge_links, b.edges.astype(np.int32)) for b in boards]
     B = args.envs
     per = -(-B // len(graphs))

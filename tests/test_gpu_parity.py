@@ -341,3 +341,46 @@ def test_device_apsp_matches_host_and_reference_distances(sy):
     two = sy.make_board(6, [[0, 1], [1, 2], [3, 4]], [2, 3, 1])
     d = _np(sy.device_all_pairs_shortest_paths(sy.pack_ell(two)[None], 6))[0].view(np.uint16)
     assert d[0, 2] == 5 and d[3, 4] == 1 and d[0, 3] == 0xFFFF and d[5, 0] == 0xFFFF and d[5, 5] == 0
+
+
+def test_partial_reset_and_reseed_match_oracle(sy, ol):
+    """sy_env_reset with an env selection (CustomEnvironment.reset of some envs) and with a new seed."""
+    env, orc, _ = _make_pair(sy, ol, 40, 30, 50, 3, 9, 2, 31, reveal_interval=4, auto_reset=False)
+    rng = np.random.default_rng(5)
+    for s in range(12):
+        act = _random_actions(rng, orc.pos, orc.mask[:, :, :30], 30)
+        env.step(torch.as_tensor(act, device=env.device))
+        orc.step(act)
+    sel = (orc.terminated | orc.truncated).astype(bool) | (np.arange(40) % 3 == 0)
+    env.reset(env_mask=torch.as_tensor(sel, device=env.device))
+    orc.reset(seed=31, env_sel=sel.astype(np.uint8))
+    _compare_state(env, orc, "after partial reset")
+    for s in range(6):
+        act = _random_actions(rng, orc.pos, orc.mask[:, :, :30], 30)
+        env.step(torch.as_tensor(act, device=env.device))
+        orc.step(act)
+    _compare_state(env, orc, "steps after partial reset")
+    env.reset(seed=77)
+    orc.reset(seed=77)
+    _compare_state(env, orc, "after reseed")
+    rec, ref = env.rollout(20), orc.rollout(20)
+    np.testing.assert_array_equal(_np(rec["action"]), ref["action"])
+    env.close()
+
+
+def test_rollout_metrics_on_device(sy):
+    from student_mechanism_design_amd import metrics as M
+    boards = sy.sample_board_pool(2, 60, 100, seed=3)
+    env = sy.BatchedScotlandYardEnv(512, boards, 4, 12, np.full(11, 0.5), seed=1, reveal_interval=5)
+    rec = env.rollout(96)
+    m = M.rollout_metrics(rec, env.N)
+    done = (_np(rec["terminated"]) | _np(rec["truncated"])).astype(bool)
+    assert int(m["num_episodes"]) == done.sum() > 0
+    assert int(m["mrx_wins"]) + int(m["police_wins"]) == done.sum()
+    assert 0.0 <= float(m["win_rate"]) <= 1.0 and float(m["mean_episode_length"]) >= 1.0
+    # at reveal steps the belief is a delta on MrX: cross-entropy ~ 0 there
+    t = _np(rec["t"])
+    ce = _np(M.belief_cross_entropy(rec["belief"][..., : env.N], rec["pos"][..., 0]))
+    reveal = (t > 0) & (t % 5 == 0)
+    assert reveal.any() and np.abs(ce[reveal]).max() < 1e-5
+    env.close()

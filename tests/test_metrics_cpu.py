@@ -1,0 +1,45 @@
+"""Rollout metrics vs the reference formulas (src/eval/metrics.py), on synthetic records (CPU)."""
+import numpy as np
+import torch
+
+from student_mechanism_design_amd import metrics as M
+
+
+def _ref_ce(belief, true_index):          # eval/metrics.py:294-306 restated with numpy
+    b = np.clip(belief, 1e-8, 1.0)
+    b = b / b.sum()
+    return float(-np.log(b[true_index]))
+
+
+def test_belief_cross_entropy_matches_reference_formula():
+    rng = np.random.default_rng(0)
+    bel = rng.random((7, 5, 12))
+    bel[0, 0] = 0.0
+    bel[0, 0, 3] = 1.0                      # a delta: CE of the true node ~ 0, of another node = -log(1e-8 / Z)
+    bel /= bel.sum(-1, keepdims=True)
+    idx = rng.integers(0, 12, (7, 5))
+    got = M.belief_cross_entropy(torch.tensor(bel), torch.tensor(idx)).numpy()
+    for i in range(7):
+        for j in range(5):
+            assert abs(got[i, j] - _ref_ce(bel[i, j], idx[i, j])) < 1e-12
+
+
+def test_rollout_metrics_aggregate_like_metrics_tracker():
+    T, B, A, N = 6, 4, 3, 10
+    rec = {
+        "terminated": torch.zeros(T, B, dtype=torch.int32), "truncated": torch.zeros(T, B, dtype=torch.int32),
+        "winner": torch.zeros(T, B, dtype=torch.int32), "t": torch.arange(T).unsqueeze(1).expand(T, B).clone().int(),
+        "budget": torch.full((T, B, A), 7, dtype=torch.int32), "pos": torch.zeros(T, B, A, dtype=torch.int32),
+        "belief": torch.full((T, B, 16), 0.1),
+    }
+    rec["belief"][..., 10:] = 0
+    # env 0: Police win at step 2 (length 3); env 1: MrX win at step 5 (length 6); env 2: MrX win by truncation at 4
+    rec["terminated"][2, 0] = 1; rec["winner"][2, 0] = 1
+    rec["terminated"][5, 1] = 1; rec["winner"][5, 1] = 2
+    rec["truncated"][4, 2] = 1; rec["winner"][4, 2] = 2
+    m = M.rollout_metrics(rec, N)
+    assert int(m["num_episodes"]) == 3 and int(m["mrx_wins"]) == 2 and int(m["police_wins"]) == 1
+    assert abs(float(m["win_rate"]) - 2 / 3) < 1e-6                    # metrics.py:196 (MrX win rate)
+    assert abs(float(m["mean_episode_length"]) - (3 + 6 + 5) / 3) < 1e-6
+    assert float(m["mean_time_to_catch"]) == 3.0 and float(m["mean_survival_time"]) == 5.5
+    assert abs(float(m["mean_belief_ce"]) - (-np.log(0.1))) < 1e-6 and float(m["belief_ce_std"]) < 1e-6

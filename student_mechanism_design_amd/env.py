@@ -186,8 +186,9 @@ class BatchedScotlandYardEnv:
         sel = None
         if env_mask is not None:
             sel = env_mask.to(device=self.device, dtype=torch.uint8).contiguous()
-        _lib.check(self.lib.sy_env_reset(self._handle, _ptr(sel), C.c_uint64(self.seed & (2**64 - 1)),
-                                         _stream_handle(self.device)), "sy_env_reset")
+        with torch.cuda.device(self.device):   # launches go to the HIP current device
+            _lib.check(self.lib.sy_env_reset(self._handle, _ptr(sel), C.c_uint64(self.seed & (2**64 - 1)),
+                                             _stream_handle(self.device)), "sy_env_reset")
         return self.observation()
 
     def reset_to(self, starts):
@@ -195,7 +196,8 @@ class BatchedScotlandYardEnv:
         st = torch.as_tensor(starts, dtype=torch.int32).to(self.device).contiguous()
         if tuple(st.shape) != (self.B, self.A):
             raise ValueError(f"starts must have shape ({self.B}, {self.A})")
-        _lib.check(self.lib.sy_env_reset_to(self._handle, _ptr(st), _stream_handle(self.device)), "sy_env_reset_to")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sy_env_reset_to(self._handle, _ptr(st), _stream_handle(self.device)), "sy_env_reset_to")
         return self.observation()
 
     def step(self, actions: torch.Tensor):
@@ -206,7 +208,8 @@ class BatchedScotlandYardEnv:
             act = torch.as_tensor(actions).to(device=self.device, dtype=torch.int32).contiguous()
         if tuple(act.shape) != (self.B, self.A):
             raise ValueError(f"actions must have shape ({self.B}, {self.A})")
-        _lib.check(self.lib.sy_env_step(self._handle, _ptr(act), _stream_handle(self.device)), "sy_env_step")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sy_env_step(self._handle, _ptr(act), _stream_handle(self.device)), "sy_env_step")
         return self.observation(), self.reward, self.terminated, self.truncated
 
     def alloc_rollout(self, T: int, record_mask=True, record_belief=True) -> Dict[str, torch.Tensor]:
@@ -236,6 +239,7 @@ class BatchedScotlandYardEnv:
         if record:
             rb = _lib.RolloutBuffers(*[out[k].data_ptr() if out.get(k) is not None else None
                                        for k in ("record", "mask", "belief")])
-        _lib.check(self.lib.sy_env_rollout(self._handle, int(T), C.byref(rb) if rb is not None else None,
-                                           _stream_handle(self.device)), "sy_env_rollout")
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sy_env_rollout(self._handle, int(T), C.byref(rb) if rb is not None else None,
+                                               _stream_handle(self.device)), "sy_env_rollout")
         return out

@@ -153,6 +153,15 @@ int sy_belief_update(const uint32_t *ell, const float *inv_deg, int32_t num_node
  * shortest paths from the ELL table, apsp uint16 [G][N][N] (0xFFFF = unreachable); all device */
 int sy_build_apsp(const uint32_t *ell, int32_t num_nodes, int32_t num_graphs, uint16_t *apsp, void *stream);
 
+/* replaces ConnectedGraph.sample / _create_tree (graph_layout.py:9-80) for a pool of boards, on device:
+ * random-Prim tree + extra edges under the degree cap (reference: 4), weights in {1..4}, own Philox
+ * streams (statistical parity).  Outputs: ell uint32 [G][N][16], inv_deg float [G][NS], the edge list
+ * in insertion order edge_links int32 [G][edge_capacity][2], edge_w int32 [G][edge_capacity], and
+ * edges_out int32 [G] = edges realised (-1: a row exceeded the ELL width, redraw that board). */
+int sy_sample_boards(int32_t num_nodes, int32_t node_stride, int32_t num_edges, int32_t max_edges_per_node, uint64_t seed,
+                     int32_t num_graphs, uint32_t *ell, float *inv_deg, int32_t *edge_links, int32_t *edge_w,
+                     int32_t *edges_out, int32_t edge_capacity, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -8,7 +8,7 @@ device classes raise `EngineError`.
 from ._lib import EngineError, LIB_PATH  # noqa: F401
 from .graph import (Board, PackedPool, make_board, sample_board, sample_board_pool, pack_pool,  # noqa: F401
                     pack_ell, all_pairs_shortest_paths, device_all_pairs_shortest_paths, reward_tables,
-                    node_stride_for)
+                    node_stride_for, DevicePool, sample_board_pool_device)
 from .env import BatchedScotlandYardEnv, REWARD_WEIGHT_NAMES, DEFAULT_ACTION, weights_to_array  # noqa: F401
 from .action_mask import compute_action_mask, get_action_mask_for_agent, ActionMaskResult  # noqa: F401
 from .belief import DeviceBeliefTracker  # noqa: F401

@@ -229,4 +229,18 @@ int sy_build_apsp(const uint32_t* ell, int32_t num_nodes, int32_t num_graphs, ui
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_build_apsp launch");
 }
 
+int sy_sample_boards(int32_t num_nodes, int32_t node_stride, int32_t num_edges, int32_t max_edges_per_node, uint64_t seed,
+                     int32_t num_graphs, uint32_t* ell, float* inv_deg, int32_t* edge_links, int32_t* edge_w,
+                     int32_t* edges_out, int32_t edge_capacity, void* stream) {
+    if (!ell || !inv_deg || !edge_links || !edge_w || !edges_out) return fail(SY_ERR_INVALID, "sy_sample_boards: null argument%s");
+    if (num_nodes < 2 || num_nodes > SY_MAX_NODES || node_stride < num_nodes || (node_stride & 15) || num_graphs < 1)
+        return fail(SY_ERR_INVALID, "sy_sample_boards: bad sizes%s");
+    if (num_edges < num_nodes - 1) num_edges = num_nodes - 1;   // minimal case for a connected graph (graph_layout.py:20-21)
+    if (edge_capacity < num_edges) return fail(SY_ERR_INVALID, "sy_sample_boards: edge_capacity < num_edges%s");
+    if (max_edges_per_node < 1 || max_edges_per_node > SY_ELL_WIDTH) return fail(SY_ERR_INVALID, "sy_sample_boards: bad degree cap%s");
+    hipError_t e = sy::launch_sample_boards(num_nodes, node_stride, num_edges, max_edges_per_node, seed, num_graphs, ell, inv_deg,
+                                            edge_links, edge_w, edges_out, edge_capacity, (hipStream_t)stream);
+    return e == hipSuccess ? SY_OK : hip_fail(e, "sy_sample_boards launch");
+}
+
 }  // extern "C"

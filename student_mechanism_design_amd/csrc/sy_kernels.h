@@ -43,4 +43,8 @@ hipError_t launch_belief_update(const uint32_t* ell, const float* inv_deg, int N
 
 hipError_t launch_apsp(const uint32_t* ell, int N, int G, uint16_t* apsp, hipStream_t stream);
 
+hipError_t launch_sample_boards(int N, int NS, int E_target, int max_deg_extra, uint64_t seed, int G, uint32_t* ell,
+                                float* inv_deg, int32_t* edge_links, int32_t* edge_w, int32_t* num_edges, int E_cap,
+                                hipStream_t stream);
+
 }  // namespace sy

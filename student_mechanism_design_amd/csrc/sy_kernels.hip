@@ -1219,6 +1219,120 @@ __global__ __launch_bounds__(256) void apsp_kernel(const uint32_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Board sampler (reset side; replaces ConnectedGraph.sample / _create_tree, graph_layout.py:9-80, for a
+// whole pool): one wave per board.
+//   tree   — random-Prim == random node order + uniform parent among the earlier nodes (an edge drawn
+//            uniformly from visited x unvisited is exactly that), built lane-parallel;
+//   extras — the reference walks a shuffled list of all non-edges and adds a pair when both degrees are
+//            below the cap.  Equivalent rejection sampling: every round each lane proposes a uniform
+//            pair, the first valid proposal in lane order is accepted (later lanes are discarded because
+//            their validity may have changed) — one accepted edge per round, failures 64 at a time;
+//   weights uniform in {1..4} (randint(1, 5)).  Own Philox streams: parity is statistical.
+// Outputs the ELL rows (sorted by neighbour), 1/deg, and the edge list in insertion order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void sample_boards_kernel(int N, int NS, int E_target, int max_deg_extra, uint32_t seed_lo,
+                                                           uint32_t seed_hi, int G, int max_rounds,
+                                                           uint32_t* __restrict__ ell, float* __restrict__ inv_deg,
+                                                           int32_t* __restrict__ edge_links, int32_t* __restrict__ edge_w,
+                                                           int32_t* __restrict__ num_edges, int E_cap) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x & 63;
+    const int g = blockIdx.x;
+    uint16_t* nbr = reinterpret_cast<uint16_t*>(smem);                 // [N][16]
+    uint8_t* wgt = reinterpret_cast<uint8_t*>(nbr + (size_t)N * kD);   // [N][16]
+    int* deg = reinterpret_cast<int*>(wgt + (size_t)N * kD);           // [N]
+    uint16_t* perm = reinterpret_cast<uint16_t*>(deg + N);             // [N]
+    int* flag = reinterpret_cast<int*>(perm + ((N + 1) & ~1));         // [2]: overflow, edge count
+    int32_t* el = edge_links + (size_t)g * E_cap * 2;
+    int32_t* ew = edge_w + (size_t)g * E_cap;
+    for (int i = lane; i < N; i += kWave) {
+        deg[i] = 0;
+        perm[i] = (uint16_t)i;
+    }
+    if (lane == 0) { flag[0] = 0; flag[1] = 0; }
+    wave_lds_fence();
+    // random node order (Fisher-Yates on one lane; N <= 1024)
+    if (lane == 0) {
+        for (int i = N - 1; i > 0; --i) {
+            uint32_t o[4];
+            philox4((uint64_t)g, (uint32_t)i, 3u, 0u, seed_lo, seed_hi, o);
+            const int j = (int)__umulhi(o[0], (uint32_t)(i + 1));
+            const uint16_t tmp = perm[i]; perm[i] = perm[j]; perm[j] = tmp;
+        }
+    }
+    wave_lds_fence();
+    // spanning tree: child perm[i], parent perm[uniform(0..i-1)]
+    for (int i = 1 + lane; i < N; i += kWave) {
+        uint32_t o[4];
+        philox4((uint64_t)g, (uint32_t)i, 4u, 0u, seed_lo, seed_hi, o);
+        const int u = perm[__umulhi(o[0], (uint32_t)i)], v = perm[i];
+        const int w = 1 + (int)__umulhi(o[1], 4u);
+        const int su = atomicAdd(&deg[u], 1), sv = atomicAdd(&deg[v], 1);
+        if (su < kD && sv < kD) {
+            nbr[u * kD + su] = (uint16_t)v; wgt[u * kD + su] = (uint8_t)w;
+            nbr[v * kD + sv] = (uint16_t)u; wgt[v * kD + sv] = (uint8_t)w;
+        } else {
+            flag[0] = 1;   // a row would exceed the ELL width: the host redraws this board
+        }
+        if (i - 1 < E_cap) { el[2 * (i - 1)] = u; el[2 * (i - 1) + 1] = v; ew[i - 1] = w; }   // (visited, new) like :66-70
+    }
+    wave_lds_fence();
+    int edges = N - 1;
+    // extra edges under the degree cap
+    for (int round = 0; round < max_rounds && edges < E_target; ++round) {
+        uint32_t o[4];
+        philox4((uint64_t)g, (uint32_t)round, 5u, (uint32_t)lane, seed_lo, seed_hi, o);
+        int a = (int)__umulhi(o[0], (uint32_t)N), b = (int)__umulhi(o[1], (uint32_t)(N - 1));
+        b += b >= a ? 1 : 0;                       // uniform unordered pair of distinct nodes
+        const int i = a < b ? a : b, j = a < b ? b : a;
+        bool ok = deg[i] < max_deg_extra && deg[j] < max_deg_extra;   // :38-43
+        if (ok) {
+            const int di = deg[i];
+            for (int q = 0; q < di; ++q) ok = ok && nbr[i * kD + q] != (uint16_t)j;   // not yet an edge (:28)
+        }
+        const uint64_t bm = __ballot(ok);
+        if (bm != 0ull) {
+            const int win = __ffsll((long long)bm) - 1;
+            if (lane == win) {
+                const int w = 1 + (int)__umulhi(o[2], 4u);
+                const int si = deg[i]++, sj = deg[j]++;
+                nbr[i * kD + si] = (uint16_t)j; wgt[i * kD + si] = (uint8_t)w;
+                nbr[j * kD + sj] = (uint16_t)i; wgt[j * kD + sj] = (uint8_t)w;
+                if (edges < E_cap) { el[2 * edges] = i; el[2 * edges + 1] = j; ew[edges] = w; }
+            }
+            ++edges;
+            wave_lds_fence();
+        }
+    }
+    wave_lds_fence();
+    // sort every row by neighbour id and emit the packed ELL row + 1/deg
+    for (int u = lane; u < NS; u += kWave) {
+        if (u < N) {
+            const int d = deg[u] < kD ? deg[u] : kD;
+            for (int x = 1; x < d; ++x) {   // insertion sort, rows have <= 16 entries
+                const uint16_t kn = nbr[u * kD + x];
+                const uint8_t kw = wgt[u * kD + x];
+                int y = x - 1;
+                while (y >= 0 && nbr[u * kD + y] > kn) {
+                    nbr[u * kD + y + 1] = nbr[u * kD + y];
+                    wgt[u * kD + y + 1] = wgt[u * kD + y];
+                    --y;
+                }
+                nbr[u * kD + y + 1] = kn;
+                wgt[u * kD + y + 1] = kw;
+            }
+            uint32_t* row = ell + ((size_t)g * N + u) * kD;
+            for (int x = 0; x < kD; ++x)
+                row[x] = x < d ? ((uint32_t)nbr[u * kD + x] | ((uint32_t)wgt[u * kD + x] << 16)) : ((uint32_t)N | 0xFFFF0000u);
+            inv_deg[(size_t)g * NS + u] = d > 0 ? 1.0f / (float)d : 0.0f;
+        } else {
+            inv_deg[(size_t)g * NS + u] = 0.0f;
+        }
+    }
+    if (lane == 0) num_edges[g] = flag[0] ? -1 : edges;
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launchers (called from the C ABI, sy_capi.hip)
 // ---------------------------------------------------------------------------------------------
 template <int NR>
@@ -1307,6 +1421,16 @@ hipError_t launch_apsp(const uint32_t* ell, int N, int G, uint16_t* apsp, hipStr
     if (nr <= 4) return launch_apsp_nr<4>(ell, N, G, apsp, stream);
     if (nr <= 8) return launch_apsp_nr<8>(ell, N, G, apsp, stream);
     return launch_apsp_nr<16>(ell, N, G, apsp, stream);
+}
+
+hipError_t launch_sample_boards(int N, int NS, int E_target, int max_deg_extra, uint64_t seed, int G, uint32_t* ell,
+                                float* inv_deg, int32_t* edge_links, int32_t* edge_w, int32_t* num_edges, int E_cap,
+                                hipStream_t stream) {
+    const size_t lds = (size_t)N * kD * 3 + (size_t)N * 4 + (size_t)((N + 1) & ~1) * 2 + 16;
+    const int max_rounds = 64 * N + 4096;
+    hipLaunchKernelGGL(sample_boards_kernel, dim3(G), dim3(64), lds, stream, N, NS, E_target, max_deg_extra, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), G, max_rounds, ell, inv_deg, edge_links, edge_w, num_edges, E_cap);
+    return hipGetLastError();
 }
 
 }  // namespace sy

@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from .graph import Board, PackedPool, pack_pool, reward_tables
+from .graph import Board, DevicePool, PackedPool, pack_pool, reward_tables
 
 # order of REWARD_WEIGHT_NAMES, src/reward_net.py:5-17
 REWARD_WEIGHT_NAMES = [
@@ -65,7 +65,11 @@ class BatchedScotlandYardEnv:
             raise _lib.EngineError("device must be a cuda (ROCm) device")
         if self.device.index is None:
             self.device = torch.device("cuda", torch.cuda.current_device())
-        self.pool = boards if isinstance(boards, PackedPool) else pack_pool(boards)
+        self._device_pool = boards if isinstance(boards, DevicePool) else None
+        if self._device_pool is not None:
+            self.pool = boards.to_packed()       # host mirror of the device-built pool (arrays only)
+        else:
+            self.pool = boards if isinstance(boards, PackedPool) else pack_pool(boards)
         self.B, self.P, self.A = int(num_envs), int(num_police), int(num_police) + 1
         self.N, self.NS, self.G = self.pool.num_nodes, self.pool.node_stride, len(self.pool.boards)
         self.agent_money, self.max_timestep = int(agent_money), int(max_timestep)
@@ -82,9 +86,14 @@ class BatchedScotlandYardEnv:
 
         dev = self.device
         # ---- graph pool (per-graph constants, resident in HBM / L2)
-        self.ell = torch.from_numpy(self.pool.ell.view(np.int32).copy()).to(dev)
-        self.apsp = torch.from_numpy(self.pool.apsp.view(np.int16).copy()).to(dev)
-        self.inv_deg = torch.from_numpy(self.pool.inv_deg).to(dev)
+        if self._device_pool is not None:            # tables were built on this GPU: use them in place
+            self.ell = self._device_pool.ell.to(dev).contiguous()
+            self.apsp = self._device_pool.apsp.to(dev).contiguous()
+            self.inv_deg = self._device_pool.inv_deg.to(dev).contiguous()
+        else:
+            self.ell = torch.from_numpy(self.pool.ell.view(np.int32).copy()).to(dev)
+            self.apsp = torch.from_numpy(self.pool.apsp.view(np.int16).copy()).to(dev)
+            self.inv_deg = torch.from_numpy(self.pool.inv_deg).to(dev)
         if env_graph is None:
             # contiguous slabs of envs per graph, aligned to launch blocks
             per = -(-self.B // self.G)

@@ -214,3 +214,79 @@ def pack_pool(boards: Sequence[Board], node_stride: Optional[int] = None) -> Pac
                       np.stack([pack_ell(b) for b in boards]),
                       np.stack([all_pairs_shortest_paths(b) for b in boards]),
                       np.stack([inverse_degree(b, ns) for b in boards]))
+
+
+class DevicePool:
+    """A board pool that was sampled and packed ON the GPU (`sy_sample_boards` + `sy_build_apsp`).
+    Device tensors: ell int32 [G,N,16] (uint32 bits), apsp int16 [G,N,N] (uint16 bits), inv_deg
+    float32 [G,NS], edge_links int32 [G,E,2], edge_w int32 [G,E]; `to_packed()` gives host copies
+    (incl. `Board` objects) for code that wants the reference's arrays."""
+
+    def __init__(self, num_nodes, node_stride, ell, apsp, inv_deg, edge_links, edge_w, num_edges):
+        self.num_nodes, self.node_stride = int(num_nodes), int(node_stride)
+        self.ell, self.apsp, self.inv_deg = ell, apsp, inv_deg
+        self.edge_links, self.edge_w, self.num_edges = edge_links, edge_w, int(num_edges)
+
+    def __len__(self):
+        return int(self.ell.shape[0])
+
+    def to_packed(self) -> PackedPool:
+        links = self.edge_links.cpu().numpy()
+        w = self.edge_w.cpu().numpy()
+        boards = [make_board(self.num_nodes, links[g, : self.num_edges], w[g, : self.num_edges]) for g in range(len(self))]
+        return PackedPool(boards, self.num_nodes, self.node_stride,
+                          self.ell.cpu().numpy().view(np.uint32), self.apsp.cpu().numpy().view(np.uint16),
+                          self.inv_deg.cpu().numpy())
+
+
+def sample_board_pool_device(num_graphs, num_nodes, num_edges, seed=0, max_edges_per_node=4, max_attempts=100,
+                             device="cuda") -> DevicePool:
+    """`sample_board_pool` on the GPU: boards with one common edge count (yard.py:65-101 — the first
+    board fixes the achievable count, the others are redrawn until they match; RuntimeError after
+    `max_attempts`).  No CPU fallback."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    if not torch.cuda.is_available():
+        raise _lib.EngineError("sample_board_pool_device needs a GPU; use sample_board_pool on the host")
+    dev = torch.device(device)
+    G, N = int(num_graphs), int(num_nodes)
+    NS = node_stride_for(N)
+    E = max(int(num_edges) if num_edges is not None else N - 1, N - 1)
+    ell = torch.empty((G, N, ELL_WIDTH), dtype=torch.int32, device=dev)
+    inv_deg = torch.empty((G, NS), dtype=torch.float32, device=dev)
+    links = torch.zeros((G, E, 2), dtype=torch.int32, device=dev)
+    w = torch.zeros((G, E), dtype=torch.int32, device=dev)
+    counts = torch.empty((G,), dtype=torch.int32, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+
+    def draw(n, s):
+        e_, i_, l_, w_, c_ = (torch.empty((n,) + tuple(t.shape[1:]), dtype=t.dtype, device=dev)
+                              for t in (ell, inv_deg, links, w, counts))
+        l_.zero_(); w_.zero_()
+        with torch.cuda.device(dev):
+            _lib.check(lib.sy_sample_boards(N, NS, E, int(max_edges_per_node), C.c_uint64(s & (2**64 - 1)), n, p(e_), p(i_),
+                                            p(l_), p(w_), p(c_), E, stream), "sy_sample_boards")
+        return e_, i_, l_, w_, c_
+
+    e_, i_, l_, w_, c_ = draw(G, int(seed))
+    ell.copy_(e_); inv_deg.copy_(i_); links.copy_(l_); w.copy_(w_); counts.copy_(c_)
+    host_counts = counts.cpu().numpy().copy()
+    valid = host_counts[host_counts >= 0]
+    if valid.size == 0:
+        raise RuntimeError("board sampler: every board exceeded the ELL width")
+    target = int(host_counts[np.argmax(host_counts >= 0)])    # the first valid board fixes the count
+    for attempt in range(1, max_attempts + 1):
+        bad = np.nonzero(host_counts != target)[0]
+        if bad.size == 0:
+            break
+        e_, i_, l_, w_, c_ = draw(int(bad.size), int(seed) + 0x9E3779B97F4A7C15 * attempt)
+        idx = torch.as_tensor(bad, device=dev, dtype=torch.long)
+        ell[idx] = e_; inv_deg[idx] = i_; links[idx] = l_; w[idx] = w_
+        host_counts[bad] = c_.cpu().numpy()
+    else:
+        raise RuntimeError(f"Failed to generate graph with {target} edges after {max_attempts} attempts.")
+    apsp = device_all_pairs_shortest_paths(ell, N, device=dev)
+    return DevicePool(N, NS, ell, apsp, inv_deg, links[:, :target].contiguous(), w[:, :target].contiguous(), target)

@@ -384,3 +384,55 @@ def test_rollout_metrics_on_device(sy):
     reveal = (t > 0) & (t % 5 == 0)
     assert reveal.any() and np.abs(ce[reveal]).max() < 1e-5
     env.close()
+
+
+def test_device_board_sampler_statistics_and_use(sy, ol):
+    """sy_sample_boards: structure of ConnectedGraph.sample (graph_layout.py:9-80) — spanning tree first,
+    extras only between nodes below the degree cap, no duplicate / self edges, weights 1..4, requested
+    edge count — and the same degree statistics as the host sampler; the pool drives the engine."""
+    N, E, G = 200, 400, 48
+    pool = sy.sample_board_pool_device(G, N, E, seed=5)
+    pk = pool.to_packed()
+    assert pool.num_edges == E and len(pk.boards) == G
+    dev_deg = []
+    for b in pk.boards:
+        assert b.num_edges == E and b.edges.min() >= 1 and b.edges.max() <= 4
+        und = {tuple(sorted(x)) for x in b.edge_links.tolist()}
+        assert len(und) == E and all(u != v for u, v in und)
+        tree, extra = b.edge_links[: N - 1], b.edge_links[N - 1:]
+        seen = {int(tree[0, 0])}
+        for u, v in tree:                       # (visited, new) pairs: a spanning tree grown Prim-style
+            assert int(u) in seen and int(v) not in seen
+            seen.add(int(v))
+        assert len(seen) == N
+        deg = np.bincount(tree.reshape(-1), minlength=N)
+        for u, v in extra:
+            assert deg[u] < 4 and deg[v] < 4
+            deg[u] += 1
+            deg[v] += 1
+        dev_deg.append(deg)
+    np.testing.assert_array_equal(pk.ell, np.stack([sy.pack_ell(b) for b in pk.boards]))
+    np.testing.assert_array_equal(pk.apsp, np.stack([sy.all_pairs_shortest_paths(b) for b in pk.boards]))
+    np.testing.assert_allclose(pk.inv_deg, np.stack([sy.graph.inverse_degree(b, pool.node_stride) for b in pk.boards]))
+    host = sy.sample_board_pool(G, N, E, seed=11)
+    host_deg = [np.bincount(b.edge_links.reshape(-1), minlength=N) for b in host]
+    hd = np.bincount(np.concatenate(dev_deg), minlength=17)[:17] / (G * N)
+    hh = np.bincount(np.concatenate(host_deg), minlength=17)[:17] / (G * N)
+    assert np.abs(hd - hh).max() < 0.02, (hd, hh)       # same degree distribution (sampling error ~0.005)
+    assert abs(np.mean([d.max() for d in dev_deg]) - np.mean([d.max() for d in host_deg])) < 1.0
+    assert len({b.edge_links.tobytes() for b in pk.boards}) == G      # boards differ
+    # unreachable edge counts: every board is redrawn to the first board's realised count
+    sat = sy.sample_board_pool_device(6, 30, 70, seed=2)
+    assert sat.num_edges < 70 and len(sat) == 6
+    tree_only = sy.sample_board_pool_device(3, 12, None, seed=1)
+    assert tree_only.num_edges == 11
+    # the device-built pool runs the engine and still matches the oracle
+    env = sy.BatchedScotlandYardEnv(64, pool, 4, 20, np.full(11, 0.5), seed=3, reveal_interval=5)
+    graphs = [ol.OracleGraph(N, b.edge_links, b.edges.astype(np.int32)) for b in pk.boards]
+    orc = ol.OracleBatch(graphs, env.env_graph_host, 64, 4, 20, node_stride=env.NS, weights=np.full(11, 0.5),
+                         tables=sy.reward_tables(), reveal_interval=5)
+    orc.reset(seed=3)
+    rec, ref = env.rollout(40), orc.rollout(40)
+    for k in ("pos", "action", "mask", "reward", "terminated"):
+        np.testing.assert_array_equal(_np(rec[k]), ref[k], err_msg=k)
+    env.close()

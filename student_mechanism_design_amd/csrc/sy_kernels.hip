@@ -115,6 +115,7 @@ __device__ __noinline__ int sample_starts(int lane, int A, int N, uint64_t gid, 
 struct ScanMap {
     int grp, col, sh, per_pass;
     int gsh;            // bit offset of this lane's group inside a pass ballot
+    int ash;            // agent role: bit offset of agent (lane & 31)'s field inside a pass ballot
     uint32_t lowmask;   // bits of the group's field below this lane's column
     bool live;
 };
@@ -126,6 +127,7 @@ __device__ __forceinline__ ScanMap make_scan_map(int lane, int gw) {
     m.live = m.grp < m.per_pass;
     m.sh = (lane % m.per_pass) * gw;   // bit offset of agent (lane)'s field inside a pass ballot
     m.gsh = m.live ? m.grp * gw : 0;
+    m.ash = ((lane & 31) % m.per_pass) * gw;
     m.lowmask = (1u << m.col) - 1u;
     return m;
 }
@@ -172,21 +174,26 @@ __device__ __forceinline__ void scan_masks(const uint32_t* ell_s, uint8_t* mrow,
 // Lane a returns the sampled action (-1 if the mask is empty) and its edge cost.
 __device__ __forceinline__ void scan_sample(const uint32_t* ell_s, uint8_t* mrow, int lane, int A, int NS, int n16,
                                             int gw, const ScanMap& sm, int pos_v, int mon_v, uint32_t x_v,
-                                            int& act_v, int& cost_v, int& quirk_cnt) {
+                                            int& act_v, int& cost_v, int& quirk_cnt, int lane_off = 0) {
+    // lane_off: first agent lane of the scanned episode (0; 32 for the second episode of a paired wave).
+    // All 64 lanes scan; only that episode's agent lanes receive results (the others keep theirs).
     for (int base16 = 0; base16 < n16; base16 += kWave)   // wave-uniform trip count
         if (base16 + lane < n16) reinterpret_cast<uint4*>(mrow)[base16 + lane] = make_uint4(0, 0, 0, 0);
     wave_lds_fence();
-    act_v = -1;
-    cost_v = 0;
-    quirk_cnt = 0;
+    const int al = lane - lane_off;
+    if (al >= 0 && al < 32) {
+        act_v = -1;
+        cost_v = 0;
+        quirk_cnt = 0;
+    }
     const uint32_t fmask = (1u << gw) - 1u;
     for (int base = 0; base < A; base += sm.per_pass) {
         const int a = base + sm.grp;
         const bool on = sm.live && a < A;
-        const int src = on ? a : 0;
+        const int src = lane_off + (on ? a : 0);
         const int pa = bperm(src << 2, pos_v);
         int ma = bperm(src << 2, mon_v);
-        const int mq = bperm((src > 0 ? src - 1 : 0) << 2, mon_v);
+        const int mq = bperm((on && a > 0 ? src - 1 : src) << 2, mon_v);
         const uint32_t xa = (uint32_t)bperm(src << 2, (int)x_v);
         ma = on ? ma : -1;
         const uint32_t ent = ell_s[(pa << 4) | sm.col];
@@ -198,13 +205,67 @@ __device__ __forceinline__ void scan_sample(const uint32_t* ell_s, uint8_t* mrow
         const int rr = (int)__umulhi(xa, (uint32_t)__popc(gfield));
         const bool chosen = own && __popc(gfield & sm.lowmask) == rr;
         const uint64_t bc = __ballot(chosen);
-        const uint32_t cf = (uint32_t)(bc >> sm.sh) & fmask;                // agent (lane)'s chosen column, one-hot
-        const int from = sm.sh + (cf ? __ffs((int)cf) - 1 : 0);
+        const uint32_t cf = (uint32_t)(bc >> sm.ash) & fmask;               // agent lane's chosen column, one-hot
+        const int from = sm.ash + (cf ? __ffs((int)cf) - 1 : 0);
         const uint32_t esel = (uint32_t)bperm(from << 2, (int)ent);
-        if (lane >= base && lane < base + sm.per_pass) {
+        if (al >= base && al < base + sm.per_pass) {
             act_v = cf ? (int)(esel & 0xffffu) : -1;
             cost_v = cf ? (int)(esel >> 16) : 0;
-            quirk_cnt = __popc((uint32_t)(bq >> sm.sh) & fmask);
+            quirk_cnt = __popc((uint32_t)(bq >> sm.ash) & fmask);
+        }
+    }
+    wave_lds_fence();
+}
+
+// Both episodes of a paired wave scanned in lockstep (same work as two scan_sample calls, but the two
+// independent dependency chains — bpermute -> ELL read -> ballots -> bpermute — overlap).
+__device__ __forceinline__ void scan_sample_pair(const uint32_t* ell_s, uint8_t* mrow0, uint8_t* mrow1, int lane, int A,
+                                                 int NS, int n16, int gw, const ScanMap& sm, int pos_v, int mon_v,
+                                                 uint32_t x_v, int& act_v, int& cost_v, int& quirk_cnt) {
+    for (int base16 = 0; base16 < n16; base16 += kWave)   // wave-uniform trip count
+        if (base16 + lane < n16) {
+            reinterpret_cast<uint4*>(mrow0)[base16 + lane] = make_uint4(0, 0, 0, 0);
+            reinterpret_cast<uint4*>(mrow1)[base16 + lane] = make_uint4(0, 0, 0, 0);
+        }
+    wave_lds_fence();
+    act_v = -1;
+    cost_v = 0;
+    quirk_cnt = 0;
+    const uint32_t fmask = (1u << gw) - 1u;
+    const bool upper = lane >= 32;
+    const int al = lane & 31;
+    for (int base = 0; base < A; base += sm.per_pass) {
+        const int a = base + sm.grp;
+        const bool on = sm.live && a < A;
+        const int s0 = on ? a : 0, s1 = 32 + s0;
+        const int q0 = (on && a > 0) ? s0 - 1 : s0, q1 = 32 + q0;
+        const int pa0 = bperm(s0 << 2, pos_v), pa1 = bperm(s1 << 2, pos_v);
+        int ma0 = bperm(s0 << 2, mon_v), ma1 = bperm(s1 << 2, mon_v);
+        const int mq0 = bperm(q0 << 2, mon_v), mq1 = bperm(q1 << 2, mon_v);
+        const uint32_t xa0 = (uint32_t)bperm(s0 << 2, (int)x_v), xa1 = (uint32_t)bperm(s1 << 2, (int)x_v);
+        ma0 = on ? ma0 : -1;
+        ma1 = on ? ma1 : -1;
+        const uint32_t ent0 = ell_s[(pa0 << 4) | sm.col], ent1 = ell_s[(pa1 << 4) | sm.col];
+        const int w0 = (int)(ent0 >> 16), w1 = (int)(ent1 >> 16);
+        const bool own0 = w0 <= ma0, own1 = w1 <= ma1;
+        const uint64_t bo0 = __ballot(own0), bo1 = __ballot(own1);
+        const uint64_t bq0 = __ballot(on && w0 <= mq0), bq1 = __ballot(on && w1 <= mq1);
+        if (own0) mrow0[a * NS + (int)(ent0 & 0xffffu)] = 1;
+        if (own1) mrow1[a * NS + (int)(ent1 & 0xffffu)] = 1;
+        const uint32_t gf0 = (uint32_t)(bo0 >> sm.gsh) & fmask, gf1 = (uint32_t)(bo1 >> sm.gsh) & fmask;
+        const int rr0 = (int)__umulhi(xa0, (uint32_t)__popc(gf0)), rr1 = (int)__umulhi(xa1, (uint32_t)__popc(gf1));
+        const bool ch0 = own0 && __popc(gf0 & sm.lowmask) == rr0, ch1 = own1 && __popc(gf1 & sm.lowmask) == rr1;
+        const uint64_t bc0 = __ballot(ch0), bc1 = __ballot(ch1);
+        // agent lanes: lower half takes episode 0's ballots, upper half episode 1's
+        const uint64_t bc = upper ? bc1 : bc0, bq = upper ? bq1 : bq0;
+        const uint32_t cf = (uint32_t)(bc >> sm.ash) & fmask;
+        const int from = sm.ash + (cf ? __ffs((int)cf) - 1 : 0);
+        const uint32_t e0s = (uint32_t)bperm(from << 2, (int)ent0), e1s = (uint32_t)bperm(from << 2, (int)ent1);
+        const uint32_t esel = upper ? e1s : e0s;
+        if (al >= base && al < base + sm.per_pass) {
+            act_v = cf ? (int)(esel & 0xffffu) : -1;
+            cost_v = cf ? (int)(esel >> 16) : 0;
+            quirk_cnt = __popc((uint32_t)(bq >> sm.ash) & fmask);
         }
     }
     wave_lds_fence();
@@ -729,40 +790,12 @@ __global__ __launch_bounds__(1024) void step_kernel(const EngineParams p, const 
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// rollout_kernel: T fused env steps per launch with the uniform-random policy (sy_env_rollout).
-// Waves [0, wpb) of a block are the move waves of its episodes; when the engine tracks a belief,
-// waves [wpb, 2*wpb) are their belief waves.  Hand-off: after step s the move wave writes one ring
-// entry {MrX node | flags, police nodes} and bumps `produced`; the belief wave records belief s,
-// waits for entry s, applies prior / reveal / diffusion and bumps `consumed`.  LDS operations of a
-// wave are performed in order, so data-then-counter needs no extra wait; all spins are bounded.
-// ---------------------------------------------------------------------------------------------
-template <int NR, bool REC, int PT>   // PT > 0: police count fixed at compile time (loops over police fully unrolled)
-__global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(const EngineParams p, const int T, const sy_rollout_buffers out_arg) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const bool has_belief = p.st.belief != nullptr;
-    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wpb = p.wpb;                          // move waves (= episodes) per block
-    const bool belief_role = wid >= wpb;            // belief wave k serves episodes 2k and 2k+1 of the block
-    const int slot = belief_role ? 2 * (wid - wpb) : wid;
-    const int P = PT > 0 ? PT : p.P, A = P + 1;
+// The belief wave of the fused rollout: serves the episodes in LDS slots `slot` and `slot + 1`
+// (a belief step is less than half a move step).  See rollout_kernel for the hand-off protocol.
+template <int NR, bool REC>
+__device__ __forceinline__ void belief_wave_run(const EngineParams& p, const LdsMap& L, const EnvLds& E, int lane, int slot,
+                                                int e, int g, int wpb, int P, int A, int T, sy_rollout_buffers out) {
     const int N = p.N, NS = p.NS, B = p.B;
-    const int e0 = blockIdx.x * wpb;
-    const int e = e0 + slot;
-    const LdsMap L = lds_map(smem, N);
-    const EnvLds E = env_lds(L.env_base, slot, p.wave_lds_bytes, A, NS);
-    int g = __builtin_amdgcn_readfirstlane(p.env_graph[e0 < B ? e0 : B - 1]);
-    g = g < 0 ? 0 : (g >= p.G ? p.G - 1 : g);
-    stage_block<true>(p, L, g, N);
-    if (!belief_role && lane == 0) {
-        E.sync[0] = 0;
-        E.sync[1] = 0;
-    }
-    __syncthreads();
-    if (e >= B) return;
-    sy_rollout_buffers out = out_arg;
-
-    if (belief_role) {
         // ================================ belief wave ================================
         // serves two episodes (slots `slot`, `slot+1`): a belief step is less than half a move step,
         // so 1.5 waves per episode keep the chip at 6 waves per SIMD with 80 VGPRs each.
@@ -818,6 +851,43 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
                 if (live1) bel_out[(size_t)(e + 1) * NS + j] = b1[r];
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rollout_kernel: T fused env steps per launch with the uniform-random policy (sy_env_rollout).
+// Waves [0, wpb) of a block are the move waves of its episodes; when the engine tracks a belief,
+// waves [wpb, 2*wpb) are their belief waves.  Hand-off: after step s the move wave writes one ring
+// entry {MrX node | flags, police nodes} and bumps `produced`; the belief wave records belief s,
+// waits for entry s, applies prior / reveal / diffusion and bumps `consumed`.  LDS operations of a
+// wave are performed in order, so data-then-counter needs no extra wait; all spins are bounded.
+// ---------------------------------------------------------------------------------------------
+template <int NR, bool REC, int PT>   // PT > 0: police count fixed at compile time (loops over police fully unrolled)
+__global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(const EngineParams p, const int T, const sy_rollout_buffers out_arg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const bool has_belief = p.st.belief != nullptr;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wpb = p.wpb;                          // move waves (= episodes) per block
+    const bool belief_role = wid >= wpb;            // belief wave k serves episodes 2k and 2k+1 of the block
+    const int slot = belief_role ? 2 * (wid - wpb) : wid;
+    const int P = PT > 0 ? PT : p.P, A = P + 1;
+    const int N = p.N, NS = p.NS, B = p.B;
+    const int e0 = blockIdx.x * wpb;
+    const int e = e0 + slot;
+    const LdsMap L = lds_map(smem, N);
+    const EnvLds E = env_lds(L.env_base, slot, p.wave_lds_bytes, A, NS);
+    int g = __builtin_amdgcn_readfirstlane(p.env_graph[e0 < B ? e0 : B - 1]);
+    g = g < 0 ? 0 : (g >= p.G ? p.G - 1 : g);
+    stage_block<true>(p, L, g, N);
+    if (!belief_role && lane == 0) {
+        E.sync[0] = 0;
+        E.sync[1] = 0;
+    }
+    __syncthreads();
+    if (e >= B) return;
+    sy_rollout_buffers out = out_arg;
+
+    if (belief_role) {
+        belief_wave_run<NR, REC>(p, L, E, lane, slot, e, g, wpb, P, A, T, out);
         return;
     }
 
@@ -992,6 +1062,367 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
     {
         uint4* dst = reinterpret_cast<uint4*>(st.mask + (size_t)e * A * NS);
         for (int i = lane; i < n16; i += kWave) dst[i] = reinterpret_cast<const uint4*>(E.mrow)[i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// rollout2_kernel: the fused rollout with PAIRED move waves.  Most of a step touches only the A <= 8
+// agent lanes, so one move wave carries two episodes: lanes 0-31 hold episode `e`, lanes 32-63 episode
+// `e + 1` (agent a on lane h*32 + a).  What was wave-uniform per episode (timestep, flags, MrX's node,
+// ...) becomes a value replicated across the 32 lanes of a half; "any lane of my half" tests read the
+// matching 32 bits of one 64-bit ballot; broadcasts from an agent lane are two v_readlane + one select.
+// Only the 64-lane ELL scan and the mask-row copies run once per episode.  Instruction count per
+// episode drops by about a third; block = wpb/2 move waves + wpb/2 belief waves (wpb even).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int hbcast(int v, int src_local, bool upper) {   // v of local lane src_local of my half
+    const int lo = rdlane(v, src_local), hi = rdlane(v, 32 + src_local);
+    return upper ? hi : lo;
+}
+__device__ __forceinline__ bool hany(bool pred, bool upper) {               // pred on any lane of my half
+    const uint64_t bm = __ballot(pred);
+    return (upper ? (uint32_t)(bm >> 32) : (uint32_t)bm) != 0u;
+}
+
+// sample_starts for both halves at once (values replicated per half instead of wave-uniform)
+__device__ __noinline__ int sample_starts2(int a, bool upper, int A, int N, uint64_t gid, uint32_t ctr, uint32_t k0,
+                                           uint32_t k1) {
+    uint32_t o[4];
+    philox4(gid, ctr, kPurposeReset, (uint32_t)a, k0, k1, o);
+    const int xv = (int)o[0];
+    int sorted[SY_MAX_AGENTS];
+#pragma unroll
+    for (int j = 0; j < SY_MAX_AGENTS; ++j) sorted[j] = 0x7fffffff;
+    int mine = 0;
+#pragma unroll
+    for (int i = 0; i < SY_MAX_AGENTS; ++i) {
+        if (i < A) {
+            const uint32_t x = (uint32_t)hbcast(xv, i, upper);
+            int r = (int)__umulhi(x, (uint32_t)(N - i));
+#pragma unroll
+            for (int j = 0; j < SY_MAX_AGENTS; ++j)
+                if (j < i) r += (r >= sorted[j]) ? 1 : 0;
+#pragma unroll
+            for (int j = SY_MAX_AGENTS - 1; j >= 0; --j) {
+                const int prev = j == 0 ? -1 : sorted[j - 1];
+                sorted[j] = sorted[j] < r ? sorted[j] : (prev < r ? r : prev);
+            }
+            if (a == i) mine = r;
+        }
+    }
+    return mine;
+}
+
+// shaped_reward for a paired wave: mn / sum are per-half vectors (reward_calculator.py:94-266)
+__device__ __forceinline__ double shaped_reward2(const RewardTabs& tb, int a, bool upper, int P, bool is_pol, int t_v,
+                                                 int qcnt, int vc, int dm, const int (&dj)[SY_MAX_AGENTS - 1],
+                                                 const Coefs<true>& kc) {
+    int mn = 0x7fffffff, sum = 0;
+#pragma unroll
+    for (int k = 1; k < SY_MAX_AGENTS; ++k) {
+        if (k <= P) {
+            const int dk = hbcast(dm, k, upper);
+            mn = dk < mn ? dk : mn;
+            sum += dk;
+        }
+    }
+    double xa, xb;
+    if (__ballot(mn >= kLdsTab || sum >= kAvgTab) == 0ull) {
+        xa = lds_f64(tb.nrc_s + mn);
+        xb = lds_f64(tb.nra_s + sum);
+    } else {
+        xa = -1.0 / ((double)mn + 1.0);
+        xb = -1.0 / ((double)sum / (double)P + 1.0);
+    }
+    double group = 0.0, prox = 0.0;
+    int overlap = 0;
+    int dor = dm | (vc < kLdsTab ? 0 : kLdsTab);
+#pragma unroll
+    for (int j = 1; j < SY_MAX_AGENTS; ++j) dor |= dj[j - 1];
+    double e_mrx, cov;
+    if (__ballot(dor >= kLdsTab) == 0ull) {
+#pragma unroll
+        for (int j = 1; j < SY_MAX_AGENTS; ++j) {
+            if (j <= P) {
+                const int dij = dj[j - 1];
+                const bool other = j != a;
+                const double ex = lds_f64(tb.exp_s + (other ? dij : kLdsTab));
+                group += ex;
+                prox += dij > 1 ? ex : 0.0;
+                overlap += (other && dij <= 1) ? 1 : 0;
+            }
+        }
+        e_mrx = lds_f64(tb.exp_s + dm);
+        cov = lds_f64(tb.cov_s + vc);
+    } else {
+#pragma unroll
+        for (int j = 1; j < SY_MAX_AGENTS; ++j) {
+            if (j <= P) {
+                const int dij = dj[j - 1];
+                const bool other = j != a;
+                const double ex = other ? exp_neg_slow(tb, dij) : 0.0;
+                group += ex;
+                prox += dij > 1 ? ex : 0.0;
+                overlap += (other && dij <= 1) ? 1 : 0;
+            }
+        }
+        e_mrx = exp_neg_slow(tb, dm);
+        cov = tb.cov_g[vc < tb.n_cov ? vc : tb.n_cov - 1];
+    }
+    const double ts = (double)t_v;
+    const double x0 = a == 0 ? xa : e_mrx, x1 = a == 0 ? xb : group;
+    const double base = ((kc.get(0) * x0 + kc.get(1) * x1) + kc.get(2) * (double)qcnt) + kc.get(3) * (kc.get(7) * ts);
+    const double pol = ((base + kc.get(4) * prox) - kc.get(5) * (double)overlap) + kc.get(6) * cov;
+    (void)is_pol;
+    return a == 0 ? base : pol;
+}
+
+template <int NR, bool REC, int PT>
+__global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p, const int T, const sy_rollout_buffers out_arg) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const bool has_belief = p.st.belief != nullptr;
+    const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wpb = p.wpb;                          // episodes per block (even)
+    const int nmove = wpb >> 1;                     // move waves: two episodes each
+    const bool belief_role = wid >= nmove;
+    const int slot = 2 * (belief_role ? wid - nmove : wid);
+    const int P = PT > 0 ? PT : p.P, A = P + 1;
+    const int N = p.N, NS = p.NS, B = p.B;
+    const int e0 = blockIdx.x * wpb;
+    const int e = e0 + slot;                        // first episode of this wave's pair
+    const LdsMap L = lds_map(smem, N);
+    const EnvLds E = env_lds(L.env_base, slot, p.wave_lds_bytes, A, NS);
+    int g = __builtin_amdgcn_readfirstlane(p.env_graph[e0 < B ? e0 : B - 1]);
+    g = g < 0 ? 0 : (g >= p.G ? p.G - 1 : g);
+    stage_block<true>(p, L, g, N);
+    const EnvLds E1 = env_lds(L.env_base, slot + 1, p.wave_lds_bytes, A, NS);
+    if (!belief_role && lane == 0) {
+        E.sync[0] = 0; E.sync[1] = 0;
+        E1.sync[0] = 0; E1.sync[1] = 0;
+    }
+    __syncthreads();
+    if (e >= B) return;
+    sy_rollout_buffers out = out_arg;
+    if (belief_role) {
+        belief_wave_run<NR, REC>(p, L, E, lane, slot, e, g, wpb, P, A, T, out);
+        return;
+    }
+
+    // ================================== paired move wave ==================================
+    const bool live1 = e + 1 < B;                   // a missing second episode shadows the first (its stores are masked)
+    const bool upper0 = lane >= 32;
+    const int a0 = lane & 31;
+    const int eh = (upper0 && live1) ? e + 1 : e;   // this lane's episode
+    const bool store_ok = !upper0 || live1;
+    const uint16_t* __restrict__ ap = p.apsp + (size_t)g * N * N;
+    const uint64_t gid = p.env_id_offset + (uint64_t)eh;
+    const int n16 = (A * NS) >> 4;
+    const ScanMap sm = make_scan_map(lane, p.scan_w);
+    Coefs<true> kc;
+    kc.s = L.kc_s + (a0 == 0 ? 0 : 8);
+    RewardTabs tb;
+    tb.exp_s = L.exp_s; tb.cov_s = L.cov_s; tb.nrc_s = L.nrc_s; tb.nra_s = L.nra_s;
+    tb.exp_g = p.exp_tab; tb.cov_g = p.cov_tab; tb.n_exp = p.n_exp; tb.n_cov = p.n_cov;
+    // per-lane views of the half's LDS slice
+    uint16_t* const vis_h = upper0 ? E1.vis_s : E.vis_s;
+    int* const rec_h = upper0 ? E1.rec_s : E.rec_s;
+    int* const ring_h = upper0 ? E1.ring : E.ring;
+    int* const sync_h = upper0 ? E1.sync : E.sync;
+    uint8_t* const mrow_h = upper0 ? E1.mrow : E.mrow;
+
+    // ---- load both episodes' state
+    int pos_v = a0 < A ? p.st.pos[(size_t)eh * A + a0] : 0;
+    int mon_v = a0 < A ? p.st.budget[(size_t)eh * A + a0] : 0;
+    int t_v = p.st.t[eh];
+    uint32_t sc_v = p.st.step_count[eh];
+    for (int i = a0; i < (NS >> 3); i += 32)
+        reinterpret_cast<uint4*>(vis_h)[i] = reinterpret_cast<const uint4*>(p.st.visits + (size_t)eh * NS)[i];
+    int rev_v = p.reveal_k > 0 ? p.reveal_k - (t_v % p.reveal_k) : 0;
+    uint32_t xw[4];
+    philox4(gid, sc_v >> 2, kPurposeAct, (uint32_t)a0, p.seed_lo, p.seed_hi, xw);
+    auto draw_word = [&xw](uint32_t c) {
+        const uint32_t m = c & 3u;
+        return m == 0 ? xw[0] : (m == 1 ? xw[1] : (m == 2 ? xw[2] : xw[3]));
+    };
+    wave_lds_fence();
+    int qcnt = 0, act_v = -1, cost_v = 0;
+    scan_sample_pair(L.ell_s, E.mrow, E1.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, draw_word(sc_v), act_v, cost_v,
+                     qcnt);
+
+    const int RW = p.rec_words;
+    const size_t BA = (size_t)B * A;
+    if (a0 < 32) rec_h[a0 + 32 * 0] = 0;
+    rec_h[32 + a0] = 0;                              // padding words of the record row stay zero
+    wave_lds_fence();
+    double rew = 0.0;
+    int term_v = 0, trunc_v = 0, win_v = 0;
+
+    for (int s = 0; s < T; ++s) {
+        int ln = lane;                               // laundered: lane predicates are recomputed every step
+        asm volatile("" : "+v"(ln));
+        const bool upper = ln >= 32;
+        const int a = ln & 31;
+        const bool is_pol = a >= 1 && a <= P;
+
+        // ---- C. moves (yard.py:161-243), both episodes at once
+        const int pos0_v = pos_v, mon0_v = mon_v;
+        const int tgt_v = act_v >= 0 ? act_v : pos_v;
+        const bool skip_v = act_v == -1 || mon_v == 0;                        // :210-215
+        {
+            const int t0 = hbcast(tgt_v, 0, upper);
+            const bool blocked = hany(is_pol && pos_v == t0, upper);          // MrX vs PRE-move police (:180-188)
+            if (!blocked && a == 0) pos_v = t0;
+        }
+        bool conf = false;
+#pragma unroll
+        for (int k = 1; k < SY_MAX_AGENTS; ++k) {
+            if (k <= P) {
+                const int tk = hbcast(tgt_v, k, upper);
+                conf = conf || (is_pol && a != k && (pos_v == tk || tgt_v == tk));
+            }
+        }
+        if (__ballot(conf) == 0ull) {                 // no police collision in either episode: order cannot matter
+            if (is_pol && !skip_v && tgt_v != pos_v) {
+                pos_v = tgt_v;
+                mon_v -= cost_v;                                              // :234-236
+            }
+        } else {                                      // exact sequential order (:191-243), harmless for a clean half
+            for (int k = 1; k <= P; ++k) {
+                const int tk = hbcast(tgt_v, k, upper);
+                const bool occ = hany(is_pol && pos_v == tk, upper);          // own node included (:231)
+                if (!occ && !skip_v && a == k) {
+                    pos_v = tk;
+                    mon_v -= cost_v;
+                }
+            }
+        }
+        const bool no_money = !hany(is_pol && !skip_v, upper);                // :191,216
+        int vc = 0;
+        if (is_pol) {                                                         // :244-245
+            vc = (int)vis_h[pos_v] + 1;
+            vis_h[pos_v] = (uint16_t)vc;
+        }
+        const int mrx_v = hbcast(pos_v, 0, upper);
+        const uint32_t rowb = (uint32_t)(pos_v * N) * 2u;
+        int dm = 0;
+        int dj[SY_MAX_AGENTS - 1];
+#pragma unroll
+        for (int j = 1; j < SY_MAX_AGENTS; ++j) dj[j - 1] = 0;
+        if (is_pol) {
+            dm = (int)*at_bytes(ap, rowb + (uint32_t)mrx_v * 2u);
+#pragma unroll
+            for (int j = 1; j < SY_MAX_AGENTS; ++j)
+                if (j <= P) dj[j - 1] = (int)*at_bytes(ap, rowb + (uint32_t)hbcast(pos_v, j, upper) * 2u);
+        }
+
+        // ---- B. record the pre-step masks (after the loads, see rollout_kernel)
+        if (REC && out.mask) {
+            uint8_t* mdst = out.mask + (size_t)eh * (size_t)(A * NS);
+            for (int i = a; i < n16; i += 32)
+                if (store_ok) reinterpret_cast<uint4*>(mdst)[i] = reinterpret_cast<const uint4*>(mrow_h)[i];
+        }
+
+        // ---- F. post-move scans (one per episode): masks, position-reward counts, next action
+        const uint32_t nxt_v = sc_v + 1u;
+        if (__ballot((nxt_v & 3u) == 0u) != 0ull) {
+            uint32_t nw[4];
+            philox4(gid, nxt_v >> 2, kPurposeAct, (uint32_t)a, p.seed_lo, p.seed_hi, nw);
+            if ((nxt_v & 3u) == 0u) { xw[0] = nw[0]; xw[1] = nw[1]; xw[2] = nw[2]; xw[3] = nw[3]; }
+        }
+        const uint32_t x_next = draw_word(nxt_v);
+        int act_n = -1, cost_n = 0;
+        scan_sample_pair(L.ell_s, E.mrow, E1.mrow, ln, A, NS, n16, p.scan_w, sm, pos_v, mon_v, x_next, act_n, cost_n, qcnt);
+
+        // ---- D. outcome priority (reward_calculator.py:63-90) and rewards
+        const bool captured = hany(is_pol && pos_v == mrx_v, upper);
+        const bool timeout = t_v > p.max_t;
+        term_v = (captured || (!timeout && no_money)) ? 1 : 0;
+        trunc_v = (!captured && timeout) ? 1 : 0;
+        win_v = captured ? 1 : ((timeout || no_money) ? 2 : 0);
+        const bool ended = (term_v | trunc_v) != 0;
+        const double shaped = shaped_reward2(tb, a, upper, P, is_pol, t_v, qcnt, vc, dm, dj, kc);
+        rew = ended ? (captured ? (a == 0 ? -1.0 : 1.0) : (a == 0 ? 1.0 : 0.0)) : shaped;
+        t_v += 1;   // yard.py:355
+        sc_v += 1u;
+        if (REC) {
+            if (a < A) {
+                rec_h[2 * a] = __double2loint(rew);
+                rec_h[2 * a + 1] = __double2hiint(rew);
+                rec_h[2 * A + a] = pos0_v;
+                rec_h[3 * A + a] = mon0_v;
+                rec_h[4 * A + a] = act_v;
+            }
+            if (a < 4) rec_h[5 * A + a] = a == 0 ? t_v - 1 : (a == 1 ? term_v : (a == 2 ? trunc_v : win_v));
+            wave_lds_fence();
+            int* rdst = out.record + (size_t)eh * RW;
+            for (int i = a; i < RW; i += 32)
+                if (store_ok) rdst[i] = rec_h[i];
+            out.record += (size_t)B * RW;
+            if (out.mask) out.mask += BA * NS;
+        }
+
+        // ---- E. next episode (auto-reset) and the hand-off to the belief wave
+        const bool need = ended && p.auto_reset != 0;
+        int flags_v = 0;
+        if (__ballot(need) != 0ull) {
+            const int st = sample_starts2(a, upper, A, N, gid, sc_v, p.seed_lo, p.seed_hi);
+            if (need) {
+                pos_v = a < A ? st : 0;
+                mon_v = a == 0 ? SY_MRX_MONEY : (a < A ? p.money0 : 0);     // yard.py:117-119
+                t_v = 0;
+                rev_v = p.reveal_k;
+                for (int i = a; i < (NS >> 3); i += 32) reinterpret_cast<uint4*>(vis_h)[i] = make_uint4(0, 0, 0, 0);
+                flags_v = 1;
+            }
+            wave_lds_fence();
+            if (rdlane((int)need, 0)) scan_sample(L.ell_s, E.mrow, ln, A, NS, n16, p.scan_w, sm, pos_v, mon_v, x_next, act_n, cost_n, qcnt, 0);
+            if (rdlane((int)need, 32)) scan_sample(L.ell_s, E1.mrow, ln, A, NS, n16, p.scan_w, sm, pos_v, mon_v, x_next, act_n, cost_n, qcnt, 32);
+        }
+        if (!need && p.reveal_k > 0) {
+            rev_v -= 1;
+            if (rev_v == 0) {        // post-increment timestep is a multiple of reveal_k
+                rev_v = p.reveal_k;
+                flags_v = 2;
+            }
+        }
+        if (has_belief) {
+            for (int spin = 0; spin < kSpinMax; ++spin) {
+                const int c0 = lds_peek(E.sync + 1), c1 = live1 ? lds_peek(E1.sync + 1) : s;
+                if (s - c0 < kRing && s - c1 < kRing) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            asm volatile("" ::: "memory");
+            int* slot_p = ring_h + (s & (kRing - 1)) * 8;
+            if (a < 8) slot_p[a] = a == 0 ? (pos_v | (flags_v << 16)) : (a <= P ? pos_v : -1);
+            asm volatile("" ::: "memory");
+            if (a == 0) lds_poke(sync_h, s + 1);
+        }
+        act_v = act_n;
+        cost_v = cost_n;
+    }
+
+    // ---- write the live state back; state pointers re-read from the kernel arguments
+    const KernargParams kq = kernarg_params();
+    sy_env_state st;
+    st.pos = kq->st.pos; st.budget = kq->st.budget; st.t = kq->st.t; st.step_count = kq->st.step_count;
+    st.visits = kq->st.visits; st.belief = kq->st.belief; st.mask = kq->st.mask; st.reward = kq->st.reward;
+    st.terminated = kq->st.terminated; st.truncated = kq->st.truncated; st.winner = kq->st.winner;
+    if (store_ok) {
+        if (a0 < A) {
+            st.pos[(size_t)eh * A + a0] = pos_v;
+            st.budget[(size_t)eh * A + a0] = mon_v;
+            st.reward[(size_t)eh * A + a0] = rew;
+        }
+        if (a0 == 0) {
+            st.t[eh] = t_v;
+            st.step_count[eh] = sc_v;
+            st.terminated[eh] = (uint8_t)term_v;
+            st.truncated[eh] = (uint8_t)trunc_v;
+            st.winner[eh] = (int8_t)win_v;
+        }
+        for (int i = a0; i < (NS >> 3); i += 32)
+            reinterpret_cast<uint4*>(st.visits + (size_t)eh * NS)[i] = reinterpret_cast<const uint4*>(vis_h)[i];
+        uint4* dst = reinterpret_cast<uint4*>(st.mask + (size_t)eh * A * NS);
+        for (int i = a0; i < n16; i += 32) dst[i] = reinterpret_cast<const uint4*>(mrow_h)[i];
     }
 }
 
@@ -1341,10 +1772,17 @@ static hipError_t launch_engine_nr(const EngineParams& p, const int32_t* actions
     if (ext) {
         hipLaunchKernelGGL((step_kernel<NR>), dim3(blocks), dim3(wpb * 64), lds, stream, p, actions);
     } else {
-        const int threads = 64 * (wpb + (p.st.belief ? (wpb + 1) / 2 : 0));   // move waves + one belief wave per 2 episodes
+        const bool paired = (wpb & 1) == 0;            // paired move waves need an even number of episodes per block
+        const int threads = paired ? 64 * (wpb / 2 + (p.st.belief ? wpb / 2 : 0))
+                                   : 64 * (wpb + (p.st.belief ? (wpb + 1) / 2 : 0));   // move waves + belief waves
 #define SY_LAUNCH_ROLLOUT(PT_)                                                                                            \
     do {                                                                                                                  \
-        if (out.record)                                                                                                   \
+        if (paired) {                                                                                                     \
+            if (out.record)                                                                                               \
+                hipLaunchKernelGGL((rollout2_kernel<NR, true, PT_>), dim3(blocks), dim3(threads), lds, stream, p, T, out); \
+            else                                                                                                          \
+                hipLaunchKernelGGL((rollout2_kernel<NR, false, PT_>), dim3(blocks), dim3(threads), lds, stream, p, T, out);\
+        } else if (out.record)                                                                                            \
             hipLaunchKernelGGL((rollout_kernel<NR, true, PT_>), dim3(blocks), dim3(threads), lds, stream, p, T, out);     \
         else                                                                                                              \
             hipLaunchKernelGGL((rollout_kernel<NR, false, PT_>), dim3(blocks), dim3(threads), lds, stream, p, T, out);    \

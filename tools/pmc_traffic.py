@@ -29,7 +29,7 @@ def per_dispatch(root, counter, kernel_substr):
 def main():
     root, out = sys.argv[1], sys.argv[2]
     fused = int(sys.argv[3]) if len(sys.argv) > 3 else 128
-    kern = 'rollout_kernel'
+    kern = 'rollout'
     fetch = per_dispatch(root + '/fetch', 'FETCH_SIZE', kern)
     write = per_dispatch(root + '/write', 'WRITE_SIZE', kern)
     assert fetch and write, 'no rollout_kernel dispatches found'

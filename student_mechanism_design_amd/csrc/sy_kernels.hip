@@ -1316,9 +1316,17 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
 
         // ---- B. record the pre-step masks (after the loads, see rollout_kernel)
         if (REC && out.mask) {
-            uint8_t* mdst = out.mask + (size_t)eh * (size_t)(A * NS);
-            for (int i = a; i < n16; i += 32)
-                if (store_ok) reinterpret_cast<uint4*>(mdst)[i] = reinterpret_cast<const uint4*>(mrow_h)[i];
+            // three 16-byte LDS reads in flight per lane (unconditional: a read past the rows is harmless),
+            // then the predicated stores; rows longer than 96 x 16 B take the tail loop
+            uint4* md = reinterpret_cast<uint4*>(out.mask + (size_t)eh * (size_t)(A * NS)) + a;
+            const uint4* mr = reinterpret_cast<const uint4*>(mrow_h) + a;
+            const uint4 v0 = mr[0], v1 = mr[32], v2 = mr[64];
+            if (store_ok) {
+                if (a < n16) md[0] = v0;
+                if (a + 32 < n16) md[32] = v1;
+                if (a + 64 < n16) md[64] = v2;
+                for (int i = 96; a + i < n16; i += 32) md[i] = mr[i];
+            }
         }
 
         // ---- F. post-move scans (one per episode): masks, position-reward counts, next action
@@ -1385,10 +1393,14 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
             }
         }
         if (has_belief) {
-            for (int spin = 0; spin < kSpinMax; ++spin) {
-                const int c0 = lds_peek(E.sync + 1), c1 = live1 ? lds_peek(E1.sync + 1) : s;
-                if (s - c0 < kRing && s - c1 < kRing) break;
-                __builtin_amdgcn_s_sleep(2);
+            // back-pressure: every kRing/2 steps make sure the belief wave is at most kRing/2 entries behind,
+            // so the ring can never be overrun in between (two fewer LDS round trips on the other steps)
+            if ((s & (kRing / 2 - 1)) == 0) {
+                for (int spin = 0; spin < kSpinMax; ++spin) {
+                    const int c0 = lds_peek(E.sync + 1), c1 = live1 ? lds_peek(E1.sync + 1) : s;
+                    if (s - c0 <= kRing / 2 && s - c1 <= kRing / 2) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
             }
             asm volatile("" ::: "memory");
             int* slot_p = ring_h + (s & (kRing - 1)) * 8;

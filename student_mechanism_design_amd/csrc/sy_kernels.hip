@@ -1125,35 +1125,32 @@ __device__ __forceinline__ double shaped_reward2(const RewardTabs& tb, int a, bo
             sum += dk;
         }
     }
-    double xa, xb;
-    if (__ballot(mn >= kLdsTab || sum >= kAvgTab) == 0ull) {
-        xa = lds_f64(tb.nrc_s + mn);
-        xb = lds_f64(tb.nra_s + sum);
-    } else {
-        xa = -1.0 / ((double)mn + 1.0);
-        xb = -1.0 / ((double)sum / (double)P + 1.0);
-    }
-    double group = 0.0, prox = 0.0;
-    int overlap = 0;
-    int dor = dm | (vc < kLdsTab ? 0 : kLdsTab);
+    int dor = dm | (vc < kLdsTab ? 0 : kLdsTab) | (sum < kAvgTab ? 0 : kLdsTab);   // mn <= dm-values <= sum
 #pragma unroll
     for (int j = 1; j < SY_MAX_AGENTS; ++j) dor |= dj[j - 1];
-    double e_mrx, cov;
+    double xa, xb, group = 0.0, prox = 0.0, e_mrx, cov;
+    int overlap = 0;
     if (__ballot(dor >= kLdsTab) == 0ull) {
+        // fast path (wave-uniform): every lookup hits the LDS tables, all reads issued back to back
+        xa = lds_f64(tb.nrc_s + mn);
+        xb = lds_f64(tb.nra_s + sum);
+        e_mrx = lds_f64(tb.exp_s + dm);
+        cov = lds_f64(tb.cov_s + vc);
+        double ex[SY_MAX_AGENTS - 1];
+#pragma unroll
+        for (int j = 1; j < SY_MAX_AGENTS; ++j) ex[j - 1] = j <= P ? lds_f64(tb.exp_s + (j != a ? dj[j - 1] : kLdsTab)) : 0.0;
 #pragma unroll
         for (int j = 1; j < SY_MAX_AGENTS; ++j) {
             if (j <= P) {
                 const int dij = dj[j - 1];
-                const bool other = j != a;
-                const double ex = lds_f64(tb.exp_s + (other ? dij : kLdsTab));
-                group += ex;
-                prox += dij > 1 ? ex : 0.0;
-                overlap += (other && dij <= 1) ? 1 : 0;
+                group += ex[j - 1];                                  // slot kLdsTab = 0.0: x + 0.0 == x
+                prox += dij > 1 ? ex[j - 1] : 0.0;
+                overlap += (j != a && dij <= 1) ? 1 : 0;
             }
         }
-        e_mrx = lds_f64(tb.exp_s + dm);
-        cov = lds_f64(tb.cov_s + vc);
     } else {
+        xa = -1.0 / ((double)mn + 1.0);
+        xb = -1.0 / ((double)sum / (double)P + 1.0);
 #pragma unroll
         for (int j = 1; j < SY_MAX_AGENTS; ++j) {
             if (j <= P) {

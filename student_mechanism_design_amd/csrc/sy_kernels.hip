@@ -599,7 +599,7 @@ __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, int N) {
     return m;
 }
 
-// Per-episode LDS slice: [sync 16 B][ring][record 256 B][belief scratch (NS+16)*4][visit counters NS*2][mask rows A*NS]
+// Per-episode LDS slice: [sync 16 B][ring][record 256 B][belief scratch (NS+16)*4][visit counters NS*4][mask rows A*NS]
 // — the fixed-size parts first, so they sit at immediate offsets from the slice base.
 struct EnvLds {
     uint8_t* mrow;
@@ -617,7 +617,7 @@ __device__ __forceinline__ EnvLds env_lds(unsigned char* base, int slot, int sli
     e.rec_s = e.ring + kRing * 8;
     e.c_s = reinterpret_cast<float*>(e.rec_s + 64);
     e.vis_s = reinterpret_cast<uint16_t*>(e.c_s + (NS + 16));
-    e.mrow = reinterpret_cast<uint8_t*>(e.vis_s + NS);
+    e.mrow = reinterpret_cast<uint8_t*>(e.vis_s + 2 * NS);   // NS*4 bytes: the paired kernel keeps 32-bit counters
     return e;
 }
 
@@ -1231,8 +1231,8 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
     int mon_v = a0 < A ? p.st.budget[(size_t)eh * A + a0] : 0;
     int t_v = p.st.t[eh];
     uint32_t sc_v = p.st.step_count[eh];
-    for (int i = a0; i < (NS >> 3); i += 32)
-        reinterpret_cast<uint4*>(vis_h)[i] = reinterpret_cast<const uint4*>(p.st.visits + (size_t)eh * NS)[i];
+    uint32_t* const vis32 = reinterpret_cast<uint32_t*>(vis_h);   // 32-bit counters: one returning LDS add per step
+    for (int i = a0; i < NS; i += 32) vis32[i] = p.st.visits[(size_t)eh * NS + i];
     int rev_v = p.reveal_k > 0 ? p.reveal_k - (t_v % p.reveal_k) : 0;
     uint32_t xw[4];
     philox4(gid, sc_v >> 2, kPurposeAct, (uint32_t)a0, p.seed_lo, p.seed_hi, xw);
@@ -1295,8 +1295,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         const bool no_money = !hany(is_pol && !skip_v, upper);                // :191,216
         int vc = 0;
         if (is_pol) {                                                         // :244-245
-            vc = (int)vis_h[pos_v] + 1;
-            vis_h[pos_v] = (uint16_t)vc;
+            vc = (int)atomicAdd(vis32 + pos_v, 1u) + 1;
         }
         const int mrx_v = hbcast(pos_v, 0, upper);
         const uint32_t rowb = (uint32_t)(pos_v * N) * 2u;
@@ -1375,7 +1374,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
                 mon_v = a == 0 ? SY_MRX_MONEY : (a < A ? p.money0 : 0);     // yard.py:117-119
                 t_v = 0;
                 rev_v = p.reveal_k;
-                for (int i = a; i < (NS >> 3); i += 32) reinterpret_cast<uint4*>(vis_h)[i] = make_uint4(0, 0, 0, 0);
+                for (int i = a; i < (NS >> 2); i += 32) reinterpret_cast<uint4*>(vis32)[i] = make_uint4(0, 0, 0, 0);
                 flags_v = 1;
             }
             wave_lds_fence();
@@ -1428,8 +1427,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
             st.truncated[eh] = (uint8_t)trunc_v;
             st.winner[eh] = (int8_t)win_v;
         }
-        for (int i = a0; i < (NS >> 3); i += 32)
-            reinterpret_cast<uint4*>(st.visits + (size_t)eh * NS)[i] = reinterpret_cast<const uint4*>(vis_h)[i];
+        for (int i = a0; i < NS; i += 32) st.visits[(size_t)eh * NS + i] = (uint16_t)vis32[i];
         uint4* dst = reinterpret_cast<uint4*>(st.mask + (size_t)eh * A * NS);
         for (int i = a0; i < n16; i += 32) dst[i] = reinterpret_cast<const uint4*>(mrow_h)[i];
     }

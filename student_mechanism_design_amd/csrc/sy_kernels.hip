@@ -1343,6 +1343,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         trunc_v = (!captured && timeout) ? 1 : 0;
         win_v = captured ? 1 : ((timeout || no_money) ? 2 : 0);
         const bool ended = (term_v | trunc_v) != 0;
+        int recw0 = 0, recw1 = 0;
         const double shaped = shaped_reward2(tb, a, upper, P, is_pol, t_v, qcnt, vc, dm, dj, kc);
         rew = ended ? (captured ? (a == 0 ? -1.0 : 1.0) : (a == 0 ? 1.0 : 0.0)) : shaped;
         t_v += 1;   // yard.py:355
@@ -1357,11 +1358,8 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
             }
             if (a < 4) rec_h[5 * A + a] = a == 0 ? t_v - 1 : (a == 1 ? term_v : (a == 2 ? trunc_v : win_v));
             wave_lds_fence();
-            int* rdst = out.record + (size_t)eh * RW;
-            for (int i = a; i < RW; i += 32)
-                if (store_ok) rdst[i] = rec_h[i];
-            out.record += (size_t)B * RW;
-            if (out.mask) out.mask += BA * NS;
+            recw0 = rec_h[a];            // the row leaves LDS now and HBM-bound at the end of the step,
+            recw1 = rec_h[a + 32];       // so its LDS round trip overlaps the reset / hand-off phase
         }
 
         // ---- E. next episode (auto-reset) and the hand-off to the belief wave
@@ -1403,6 +1401,15 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
             if (a < 8) slot_p[a] = a == 0 ? (pos_v | (flags_v << 16)) : (a <= P ? pos_v : -1);
             asm volatile("" ::: "memory");
             if (a == 0) lds_poke(sync_h, s + 1);
+        }
+        if (REC) {
+            int* rdst = out.record + (size_t)eh * RW;
+            if (store_ok) {
+                if (a < RW) rdst[a] = recw0;
+                if (a + 32 < RW) rdst[a + 32] = recw1;
+            }
+            out.record += (size_t)B * RW;
+            if (out.mask) out.mask += BA * NS;
         }
         act_v = act_n;
         cost_v = cost_n;

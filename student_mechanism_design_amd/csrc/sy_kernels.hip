@@ -218,10 +218,37 @@ __device__ __forceinline__ void scan_sample(const uint32_t* ell_s, uint8_t* mrow
 }
 
 // Both episodes of a paired wave scanned in lockstep (same work as two scan_sample calls, but the two
-// independent dependency chains — bpermute -> ELL read -> ballots -> bpermute — overlap).
-__device__ __forceinline__ void scan_sample_pair(const uint32_t* ell_s, uint8_t* mrow0, uint8_t* mrow1, int lane, int A,
-                                                 int NS, int n16, int gw, const ScanMap& sm, int pos_v, int mon_v,
-                                                 uint32_t x_v, int& act_v, int& cost_v, int& quirk_cnt) {
+// independent dependency chains — bpermute -> ELL read -> ballots -> bpermute — overlap).  Split in
+// two so the gather half (two dependent LDS round trips) can be issued right after the moves and
+// overlap the visit / shortest-path / mask-copy phases; the evaluate half runs where the scan was.
+struct ScanPairIn {   // first-pass operands of both episodes, one set per scan lane
+    uint32_t ent0, ent1, xa0, xa1;
+    int ma0, ma1, mq0, mq1;
+};
+__device__ __forceinline__ ScanPairIn scan_gather_pair(const uint32_t* ell_s, int A, const ScanMap& sm, int base, int pos_v,
+                                                       int mon_v, uint32_t x_v) {
+    ScanPairIn g;
+    const int a = base + sm.grp;
+    const bool on = sm.live && a < A;
+    const int s0 = on ? a : 0, s1 = 32 + s0;
+    const int q0 = (on && a > 0) ? s0 - 1 : s0, q1 = 32 + q0;
+    const int pa0 = bperm(s0 << 2, pos_v), pa1 = bperm(s1 << 2, pos_v);
+    g.ma0 = bperm(s0 << 2, mon_v);
+    g.ma1 = bperm(s1 << 2, mon_v);
+    g.mq0 = bperm(q0 << 2, mon_v);
+    g.mq1 = bperm(q1 << 2, mon_v);
+    g.xa0 = (uint32_t)bperm(s0 << 2, (int)x_v);
+    g.xa1 = (uint32_t)bperm(s1 << 2, (int)x_v);
+    g.ma0 = on ? g.ma0 : -1;
+    g.ma1 = on ? g.ma1 : -1;
+    g.ent0 = ell_s[(pa0 << 4) | sm.col];
+    g.ent1 = ell_s[(pa1 << 4) | sm.col];
+    return g;
+}
+
+__device__ __forceinline__ void scan_eval_pair(const uint32_t* ell_s, uint8_t* mrow0, uint8_t* mrow1, int lane, int A, int NS,
+                                               int n16, int gw, const ScanMap& sm, ScanPairIn g, int pos_v, int mon_v,
+                                               uint32_t x_v, int& act_v, int& cost_v, int& quirk_cnt) {
     for (int base16 = 0; base16 < n16; base16 += kWave)   // wave-uniform trip count
         if (base16 + lane < n16) {
             reinterpret_cast<uint4*>(mrow0)[base16 + lane] = make_uint4(0, 0, 0, 0);
@@ -235,32 +262,24 @@ __device__ __forceinline__ void scan_sample_pair(const uint32_t* ell_s, uint8_t*
     const bool upper = lane >= 32;
     const int al = lane & 31;
     for (int base = 0; base < A; base += sm.per_pass) {
+        if (base > 0) g = scan_gather_pair(ell_s, A, sm, base, pos_v, mon_v, x_v);   // further passes: gather inline
         const int a = base + sm.grp;
         const bool on = sm.live && a < A;
-        const int s0 = on ? a : 0, s1 = 32 + s0;
-        const int q0 = (on && a > 0) ? s0 - 1 : s0, q1 = 32 + q0;
-        const int pa0 = bperm(s0 << 2, pos_v), pa1 = bperm(s1 << 2, pos_v);
-        int ma0 = bperm(s0 << 2, mon_v), ma1 = bperm(s1 << 2, mon_v);
-        const int mq0 = bperm(q0 << 2, mon_v), mq1 = bperm(q1 << 2, mon_v);
-        const uint32_t xa0 = (uint32_t)bperm(s0 << 2, (int)x_v), xa1 = (uint32_t)bperm(s1 << 2, (int)x_v);
-        ma0 = on ? ma0 : -1;
-        ma1 = on ? ma1 : -1;
-        const uint32_t ent0 = ell_s[(pa0 << 4) | sm.col], ent1 = ell_s[(pa1 << 4) | sm.col];
-        const int w0 = (int)(ent0 >> 16), w1 = (int)(ent1 >> 16);
-        const bool own0 = w0 <= ma0, own1 = w1 <= ma1;
+        const int w0 = (int)(g.ent0 >> 16), w1 = (int)(g.ent1 >> 16);
+        const bool own0 = w0 <= g.ma0, own1 = w1 <= g.ma1;
         const uint64_t bo0 = __ballot(own0), bo1 = __ballot(own1);
-        const uint64_t bq0 = __ballot(on && w0 <= mq0), bq1 = __ballot(on && w1 <= mq1);
-        if (own0) mrow0[a * NS + (int)(ent0 & 0xffffu)] = 1;
-        if (own1) mrow1[a * NS + (int)(ent1 & 0xffffu)] = 1;
+        const uint64_t bq0 = __ballot(on && w0 <= g.mq0), bq1 = __ballot(on && w1 <= g.mq1);
+        if (own0) mrow0[a * NS + (int)(g.ent0 & 0xffffu)] = 1;
+        if (own1) mrow1[a * NS + (int)(g.ent1 & 0xffffu)] = 1;
         const uint32_t gf0 = (uint32_t)(bo0 >> sm.gsh) & fmask, gf1 = (uint32_t)(bo1 >> sm.gsh) & fmask;
-        const int rr0 = (int)__umulhi(xa0, (uint32_t)__popc(gf0)), rr1 = (int)__umulhi(xa1, (uint32_t)__popc(gf1));
+        const int rr0 = (int)__umulhi(g.xa0, (uint32_t)__popc(gf0)), rr1 = (int)__umulhi(g.xa1, (uint32_t)__popc(gf1));
         const bool ch0 = own0 && __popc(gf0 & sm.lowmask) == rr0, ch1 = own1 && __popc(gf1 & sm.lowmask) == rr1;
         const uint64_t bc0 = __ballot(ch0), bc1 = __ballot(ch1);
         // agent lanes: lower half takes episode 0's ballots, upper half episode 1's
         const uint64_t bc = upper ? bc1 : bc0, bq = upper ? bq1 : bq0;
         const uint32_t cf = (uint32_t)(bc >> sm.ash) & fmask;
         const int from = sm.ash + (cf ? __ffs((int)cf) - 1 : 0);
-        const uint32_t e0s = (uint32_t)bperm(from << 2, (int)ent0), e1s = (uint32_t)bperm(from << 2, (int)ent1);
+        const uint32_t e0s = (uint32_t)bperm(from << 2, (int)g.ent0), e1s = (uint32_t)bperm(from << 2, (int)g.ent1);
         const uint32_t esel = upper ? e1s : e0s;
         if (al >= base && al < base + sm.per_pass) {
             act_v = cf ? (int)(esel & 0xffffu) : -1;
@@ -269,6 +288,13 @@ __device__ __forceinline__ void scan_sample_pair(const uint32_t* ell_s, uint8_t*
         }
     }
     wave_lds_fence();
+}
+
+__device__ __forceinline__ void scan_sample_pair(const uint32_t* ell_s, uint8_t* mrow0, uint8_t* mrow1, int lane, int A,
+                                                 int NS, int n16, int gw, const ScanMap& sm, int pos_v, int mon_v,
+                                                 uint32_t x_v, int& act_v, int& cost_v, int& quirk_cnt) {
+    const ScanPairIn g = scan_gather_pair(ell_s, A, sm, 0, pos_v, mon_v, x_v);
+    scan_eval_pair(ell_s, mrow0, mrow1, lane, A, NS, n16, gw, sm, g, pos_v, mon_v, x_v, act_v, cost_v, quirk_cnt);
 }
 
 // Membership test `action in possible_positions` (yard.py:168,218) for caller-given actions:
@@ -1293,6 +1319,15 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
             }
         }
         const bool no_money = !hany(is_pol && !skip_v, upper);                // :191,216
+        // next step's draw + the gather half of the post-move scan, issued now (see scan_gather_pair)
+        const uint32_t nxt_v = sc_v + 1u;
+        if (__ballot((nxt_v & 3u) == 0u) != 0ull) {
+            uint32_t nw[4];
+            philox4(gid, nxt_v >> 2, kPurposeAct, (uint32_t)a, p.seed_lo, p.seed_hi, nw);
+            if ((nxt_v & 3u) == 0u) { xw[0] = nw[0]; xw[1] = nw[1]; xw[2] = nw[2]; xw[3] = nw[3]; }
+        }
+        const uint32_t x_next = draw_word(nxt_v);
+        const ScanPairIn sg = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, x_next);
         int vc = 0;
         if (is_pol) {                                                         // :244-245
             vc = (int)atomicAdd(vis32 + pos_v, 1u) + 1;
@@ -1325,16 +1360,9 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
             }
         }
 
-        // ---- F. post-move scans (one per episode): masks, position-reward counts, next action
-        const uint32_t nxt_v = sc_v + 1u;
-        if (__ballot((nxt_v & 3u) == 0u) != 0ull) {
-            uint32_t nw[4];
-            philox4(gid, nxt_v >> 2, kPurposeAct, (uint32_t)a, p.seed_lo, p.seed_hi, nw);
-            if ((nxt_v & 3u) == 0u) { xw[0] = nw[0]; xw[1] = nw[1]; xw[2] = nw[2]; xw[3] = nw[3]; }
-        }
-        const uint32_t x_next = draw_word(nxt_v);
+        // ---- F. evaluate half of the post-move scan: masks, position-reward counts, next action
         int act_n = -1, cost_n = 0;
-        scan_sample_pair(L.ell_s, E.mrow, E1.mrow, ln, A, NS, n16, p.scan_w, sm, pos_v, mon_v, x_next, act_n, cost_n, qcnt);
+        scan_eval_pair(L.ell_s, E.mrow, E1.mrow, ln, A, NS, n16, p.scan_w, sm, sg, pos_v, mon_v, x_next, act_n, cost_n, qcnt);
 
         // ---- D. outcome priority (reward_calculator.py:63-90) and rewards
         const bool captured = hany(is_pol && pos_v == mrx_v, upper);

@@ -1109,6 +1109,31 @@ __device__ __forceinline__ bool hany(bool pred, bool upper) {               // p
     return (upper ? (uint32_t)(bm >> 32) : (uint32_t)bm) != 0u;
 }
 
+// Mask algebra for paired waves: predicates that are uniform per half are kept as 64-bit lane masks in
+// SGPRs and combined with scalar instructions; only the primitive compares are vector work.
+__device__ __forceinline__ uint64_t bal(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool lanes(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+static constexpr uint64_t kLowHalf = 0x00000000ffffffffull, kHighHalf = 0xffffffff00000000ull;
+__device__ __forceinline__ uint64_t half_any(uint64_t m) {      // each half all-ones iff any of its bits is set
+    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+    const uint32_t mlo = lo ? ~0u : 0u, mhi = hi ? ~0u : 0u;
+    return ((uint64_t)mhi << 32) | mlo;
+}
+__device__ __forceinline__ uint64_t half_pick(uint64_t lo_src, uint64_t hi_src) {
+    return (lo_src & kLowHalf) | (hi_src & kHighHalf);
+}
+// lane i <- lane i - D inside its row of 16 (agents of a half sit on lanes 0..7 of a row); zero fill
+template <int D>
+__device__ __forceinline__ int dpp_shr(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x110 + D, 0xf, 0xf, true);
+}
+// Police pairs (k - D, k): does either one target the other's node or the same node?  Evaluated on lane k.
+template <int D>
+__device__ __forceinline__ uint64_t pair_conflicts(int tgt_v, int pos_v) {
+    const int st = dpp_shr<D>(tgt_v), sp = dpp_shr<D>(pos_v);
+    return bal(tgt_v == st) | bal(tgt_v == sp) | bal(pos_v == st);
+}
+
 // sample_starts for both halves at once (values replicated per half instead of wave-uniform)
 __device__ __noinline__ int sample_starts2(int a, bool upper, int A, int N, uint64_t gid, uint32_t ctr, uint32_t k0,
                                            uint32_t k1) {
@@ -1199,6 +1224,22 @@ __device__ __forceinline__ double shaped_reward2(const RewardTabs& tb, int a, bo
     return a == 0 ? base : pol;
 }
 
+// Diagnostic phase timers (-DSY_STAMPS builds only; each stamp drains the LDS queue, so the build is
+// for attribution, not for benchmarking).
+#ifdef SY_STAMPS
+#define SY_STAMP_DECL unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
+#define SY_STAMP(i) { const unsigned long long stamp_n = __builtin_amdgcn_s_memtime(); stamp_acc[i] += stamp_n - stamp_t; stamp_t = stamp_n; }
+#define SY_STAMP_DUMP(T) if (blockIdx.x == 7 && threadIdx.x == 0) printf("stamps/step: C %llu G %llu V %llu B %llu F %llu D %llu R %llu E %llu S %llu\n", stamp_acc[0] / T, stamp_acc[1] / T, stamp_acc[2] / T, stamp_acc[3] / T, stamp_acc[4] / T, stamp_acc[5] / T, stamp_acc[6] / T, stamp_acc[7] / T, stamp_acc[8] / T);
+#elif defined(SY_PHASES)   // static census builds: tools/asm_phase_count.py reads the markers from the assembly
+#define SY_STAMP_DECL
+#define SY_STAMP(i) asm volatile("; ##PHASE P" #i);
+#define SY_STAMP_DUMP(T) asm volatile("; ##PHASE epilogue");
+#else
+#define SY_STAMP_DECL
+#define SY_STAMP(i)
+#define SY_STAMP_DUMP(T)
+#endif
+
 template <int NR, bool REC, int PT>
 __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p, const int T, const sy_rollout_buffers out_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1278,37 +1319,41 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
     wave_lds_fence();
     double rew = 0.0;
     int term_v = 0, trunc_v = 0, win_v = 0;
+    const uint64_t POLM = (((1ull << P) - 1ull) << 1) * 0x0000000100000001ull;   // police lanes of both halves
+    constexpr uint64_t kMrxLanes = 0x0000000100000001ull;
 
+    SY_STAMP_DECL
     for (int s = 0; s < T; ++s) {
         int ln = lane;                               // laundered: lane predicates are recomputed every step
         asm volatile("" : "+v"(ln));
         const bool upper = ln >= 32;
         const int a = ln & 31;
         const bool is_pol = a >= 1 && a <= P;
+        SY_STAMP(8)
 
         // ---- C. moves (yard.py:161-243), both episodes at once
         const int pos0_v = pos_v, mon0_v = mon_v;
         const int tgt_v = act_v >= 0 ? act_v : pos_v;
-        const bool skip_v = act_v == -1 || mon_v == 0;                        // :210-215
-        {
-            const int t0 = hbcast(tgt_v, 0, upper);
-            const bool blocked = hany(is_pol && pos_v == t0, upper);          // MrX vs PRE-move police (:180-188)
-            if (!blocked && a == 0) pos_v = t0;
+        const uint64_t SK = bal(act_v == -1) | bal(mon_v == 0);               // skipped agents (:210-215)
+        {   // MrX vs PRE-move police (:180-188)
+            const int t_lo = rdlane(tgt_v, 0), t_hi = rdlane(tgt_v, 32);
+            const uint64_t hit = half_pick(bal(pos_v == t_lo), bal(pos_v == t_hi)) & POLM;
+            pos_v = lanes(kMrxLanes & ~half_any(hit)) ? tgt_v : pos_v;
         }
-        bool conf = false;
-#pragma unroll
-        for (int k = 1; k < SY_MAX_AGENTS; ++k) {
-            if (k <= P) {
-                const int tk = hbcast(tgt_v, k, upper);
-                conf = conf || (is_pol && a != k && (pos_v == tk || tgt_v == tk));
-            }
-        }
-        if (__ballot(conf) == 0ull) {                 // no police collision in either episode: order cannot matter
-            if (is_pol && !skip_v && tgt_v != pos_v) {
-                pos_v = tgt_v;
-                mon_v -= cost_v;                                              // :234-236
-            }
+        // any police pair that could interact this step (same target, or one moving onto the other's node)?
+        uint64_t CF = 0;
+        if (1 < P) CF |= pair_conflicts<1>(tgt_v, pos_v) & (POLM & (POLM << 1));
+        if (2 < P) CF |= pair_conflicts<2>(tgt_v, pos_v) & (POLM & (POLM << 2));
+        if (3 < P) CF |= pair_conflicts<3>(tgt_v, pos_v) & (POLM & (POLM << 3));
+        if (4 < P) CF |= pair_conflicts<4>(tgt_v, pos_v) & (POLM & (POLM << 4));
+        if (5 < P) CF |= pair_conflicts<5>(tgt_v, pos_v) & (POLM & (POLM << 5));
+        if (6 < P) CF |= pair_conflicts<6>(tgt_v, pos_v) & (POLM & (POLM << 6));
+        if (CF == 0ull) {                              // no police collision in either episode: order cannot matter
+            const uint64_t mv = POLM & ~SK & bal(tgt_v != pos_v);
+            pos_v = lanes(mv) ? tgt_v : pos_v;
+            mon_v -= lanes(mv) ? cost_v : 0;                                  // :234-236
         } else {                                      // exact sequential order (:191-243), harmless for a clean half
+            const bool skip_v = lanes(SK);
             for (int k = 1; k <= P; ++k) {
                 const int tk = hbcast(tgt_v, k, upper);
                 const bool occ = hany(is_pol && pos_v == tk, upper);          // own node included (:231)
@@ -1318,7 +1363,8 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
                 }
             }
         }
-        const bool no_money = !hany(is_pol && !skip_v, upper);                // :191,216
+        const bool no_money = lanes(~half_any(POLM & ~SK));                   // :191,216
+        SY_STAMP(0)
         // next step's draw + the gather half of the post-move scan, issued now (see scan_gather_pair)
         const uint32_t nxt_v = sc_v + 1u;
         if (__ballot((nxt_v & 3u) == 0u) != 0ull) {
@@ -1328,6 +1374,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         }
         const uint32_t x_next = draw_word(nxt_v);
         const ScanPairIn sg = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, x_next);
+        SY_STAMP(1)
         int vc = 0;
         if (is_pol) {                                                         // :244-245
             vc = (int)atomicAdd(vis32 + pos_v, 1u) + 1;
@@ -1345,6 +1392,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
                 if (j <= P) dj[j - 1] = (int)*at_bytes(ap, rowb + (uint32_t)hbcast(pos_v, j, upper) * 2u);
         }
 
+        SY_STAMP(2)
         // ---- B. record the pre-step masks (after the loads, see rollout_kernel)
         if (REC && out.mask) {
             // three 16-byte LDS reads in flight per lane (unconditional: a read past the rows is harmless),
@@ -1360,9 +1408,11 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
             }
         }
 
+        SY_STAMP(3)
         // ---- F. evaluate half of the post-move scan: masks, position-reward counts, next action
         int act_n = -1, cost_n = 0;
         scan_eval_pair(L.ell_s, E.mrow, E1.mrow, ln, A, NS, n16, p.scan_w, sm, sg, pos_v, mon_v, x_next, act_n, cost_n, qcnt);
+        SY_STAMP(4)
 
         // ---- D. outcome priority (reward_calculator.py:63-90) and rewards
         const bool captured = hany(is_pol && pos_v == mrx_v, upper);
@@ -1376,6 +1426,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         rew = ended ? (captured ? (a == 0 ? -1.0 : 1.0) : (a == 0 ? 1.0 : 0.0)) : shaped;
         t_v += 1;   // yard.py:355
         sc_v += 1u;
+        SY_STAMP(5)
         if (REC) {
             if (a < A) {
                 rec_h[2 * a] = __double2loint(rew);
@@ -1390,6 +1441,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
             recw1 = rec_h[a + 32];       // so its LDS round trip overlaps the reset / hand-off phase
         }
 
+        SY_STAMP(6)
         // ---- E. next episode (auto-reset) and the hand-off to the belief wave
         const bool need = ended && p.auto_reset != 0;
         int flags_v = 0;
@@ -1441,7 +1493,9 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         }
         act_v = act_n;
         cost_v = cost_n;
+        SY_STAMP(7)
     }
+    SY_STAMP_DUMP(T)
 
     // ---- write the live state back; state pointers re-read from the kernel arguments
     const KernargParams kq = kernarg_params();

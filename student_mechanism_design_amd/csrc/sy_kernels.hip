@@ -46,6 +46,32 @@ __device__ __forceinline__ void wave_lds_fence() {
 __device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ int bperm(int byte_addr, int v) { return __builtin_amdgcn_ds_bpermute(byte_addr, v); }
 
+// Mask algebra for paired waves: predicates that are uniform per half are kept as 64-bit lane masks in
+// SGPRs and combined with scalar instructions; only the primitive compares are vector work.
+__device__ __forceinline__ uint64_t bal(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ bool lanes(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+static constexpr uint64_t kLowHalf = 0x00000000ffffffffull, kHighHalf = 0xffffffff00000000ull;
+__device__ __forceinline__ uint64_t half_any(uint64_t m) {      // each half all-ones iff any of its bits is set
+    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+    const uint32_t mlo = lo ? ~0u : 0u, mhi = hi ? ~0u : 0u;
+    return ((uint64_t)mhi << 32) | mlo;
+}
+__device__ __forceinline__ uint64_t half_pick(uint64_t lo_src, uint64_t hi_src) {
+    return (lo_src & kLowHalf) | (hi_src & kHighHalf);
+}
+// lane i <- lane i - D inside its row of 16 (agents of a half sit on lanes 0..7 of a row); zero fill
+template <int D>
+__device__ __forceinline__ int dpp_shr(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x110 + D, 0xf, 0xf, true);
+}
+// Police pairs (k - D, k): does either one target the other's node or the same node?  Evaluated on lane k.
+template <int D>
+__device__ __forceinline__ uint64_t pair_conflicts(int tgt_v, int pos_v) {
+    const int st = dpp_shr<D>(tgt_v), sp = dpp_shr<D>(pos_v);
+    return bal(tgt_v == st) | bal(tgt_v == sp) | bal(pos_v == st);
+}
+
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_mov(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
@@ -239,8 +265,6 @@ __device__ __forceinline__ ScanPairIn scan_gather_pair(const uint32_t* ell_s, in
     g.mq1 = bperm(q1 << 2, mon_v);
     g.xa0 = (uint32_t)bperm(s0 << 2, (int)x_v);
     g.xa1 = (uint32_t)bperm(s1 << 2, (int)x_v);
-    g.ma0 = on ? g.ma0 : -1;
-    g.ma1 = on ? g.ma1 : -1;
     g.ent0 = ell_s[(pa0 << 4) | sm.col];
     g.ent1 = ell_s[(pa1 << 4) | sm.col];
     return g;
@@ -266,7 +290,7 @@ __device__ __forceinline__ void scan_eval_pair(const uint32_t* ell_s, uint8_t* m
         const int a = base + sm.grp;
         const bool on = sm.live && a < A;
         const int w0 = (int)(g.ent0 >> 16), w1 = (int)(g.ent1 >> 16);
-        const bool own0 = w0 <= g.ma0, own1 = w1 <= g.ma1;
+        const bool own0 = on && w0 <= g.ma0, own1 = on && w1 <= g.ma1;
         const uint64_t bo0 = __ballot(own0), bo1 = __ballot(own1);
         const uint64_t bq0 = __ballot(on && w0 <= g.mq0), bq1 = __ballot(on && w1 <= g.mq1);
         if (own0) mrow0[a * NS + (int)(g.ent0 & 0xffffu)] = 1;
@@ -1100,6 +1124,75 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
 // Only the 64-lane ELL scan and the mask-row copies run once per episode.  Instruction count per
 // episode drops by about a third; block = wpb/2 move waves + wpb/2 belief waves (wpb even).
 // ---------------------------------------------------------------------------------------------
+// Single-pass form of scan_eval_pair (all A agents fit one pass — the common case).  Vector work is
+// cut to the primitive compares: the ballots are combined as scalar masks; instead of clearing the
+// whole mask rows, every scan lane clears the one byte it set on the previous step; the chosen
+// entry and the position-reward count reach the agent lanes through a two-word LDS slot per agent
+// (words 48.. of the record staging row, never stored) instead of ballot shifts and a bpermute.
+struct PairScanLane {        // per-lane constants (LDS byte offsets) + the two carried "previous byte" offsets
+    uint32_t row0, row1;     // mask row of my group's agent, episode 0 / 1
+    uint32_t selw0, selw1;   // my group's slot, episode 0 / 1 (scan-lane role)
+    uint32_t selr;           // slot of agent (lane & 7) of my half (agent-lane role)
+    uint32_t prev0, prev1;
+    uint64_t on_m, lead_m;   // lanes scanning a real agent; the first lane of each such group
+};
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(3))) T* lds_at(uint32_t off) {   // LDS byte offset -> typed LDS pointer
+    return (__attribute__((address_space(3))) T*)(uintptr_t)off;
+}
+__device__ __forceinline__ uint32_t lds_off(const void* q) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)q; }
+static constexpr int kSelWord = 48, kDummyWord = 47;
+static constexpr uint64_t kAgentSlots = 0x000000ff000000ffull;   // lanes 0..7 of both halves
+
+__device__ __forceinline__ PairScanLane make_pair_scan_lane(const EnvLds& E, const EnvLds& E1, const ScanMap& sm, int lane,
+                                                            int A, int NS) {
+    PairScanLane q;
+    const bool on = sm.live && sm.grp < A;
+    q.row0 = lds_off(E.mrow) + (uint32_t)(sm.grp * NS);
+    q.row1 = lds_off(E1.mrow) + (uint32_t)(sm.grp * NS);
+    q.selw0 = lds_off(E.rec_s) + (uint32_t)(kSelWord + 2 * (sm.grp & 7)) * 4u;
+    q.selw1 = lds_off(E1.rec_s) + (uint32_t)(kSelWord + 2 * (sm.grp & 7)) * 4u;
+    const uint32_t rec_h = lane >= 32 ? lds_off(E1.rec_s) : lds_off(E.rec_s);
+    q.selr = rec_h + (uint32_t)(kSelWord + 2 * (lane & 7)) * 4u;
+    q.prev0 = lds_off(E.rec_s) + kDummyWord * 4u;
+    q.prev1 = lds_off(E1.rec_s) + kDummyWord * 4u;
+    q.on_m = bal(on);
+    q.lead_m = bal(on && sm.col == 0);
+    return q;
+}
+
+__device__ __forceinline__ void scan_eval_pair1(PairScanLane& q, const ScanMap& sm, int gw, const ScanPairIn& g, int& act_v,
+                                                int& cost_v, int& quirk_cnt) {
+    if (lanes(kAgentSlots)) *lds_at<uint64_t>(q.selr) = 0x0000ffffull;   // "no move": action -1, cost 0
+    *lds_at<uint8_t>(q.prev0) = 0;
+    *lds_at<uint8_t>(q.prev1) = 0;
+    const uint32_t fmask = (1u << gw) - 1u;
+    const int w0 = (int)(g.ent0 >> 16), w1 = (int)(g.ent1 >> 16);
+    const uint64_t bo0 = bal(w0 <= g.ma0) & q.on_m, bo1 = bal(w1 <= g.ma1) & q.on_m;
+    const uint64_t bq0 = bal(w0 <= g.mq0) & q.on_m, bq1 = bal(w1 <= g.mq1) & q.on_m;
+    const bool own0 = lanes(bo0), own1 = lanes(bo1);
+    const uint32_t n0 = q.row0 + (g.ent0 & 0xffffu), n1 = q.row1 + (g.ent1 & 0xffffu);
+    if (own0) *lds_at<uint8_t>(n0) = 1;
+    if (own1) *lds_at<uint8_t>(n1) = 1;
+    q.prev0 = own0 ? n0 : q.prev0;
+    q.prev1 = own1 ? n1 : q.prev1;
+    const uint32_t gf0 = (uint32_t)(bo0 >> sm.gsh) & fmask, gf1 = (uint32_t)(bo1 >> sm.gsh) & fmask;
+    const int rr0 = (int)__umulhi(g.xa0, (uint32_t)__popc(gf0)), rr1 = (int)__umulhi(g.xa1, (uint32_t)__popc(gf1));
+    const uint64_t ch0 = bal(__popc(gf0 & sm.lowmask) == rr0) & bo0, ch1 = bal(__popc(gf1 & sm.lowmask) == rr1) & bo1;
+    if (lanes(ch0)) *lds_at<int>(q.selw0) = (int)g.ent0;
+    if (lanes(ch1)) *lds_at<int>(q.selw1) = (int)g.ent1;
+    if (lanes(q.lead_m)) {
+        lds_at<int>(q.selw0)[1] = __popc((uint32_t)(bq0 >> sm.gsh) & fmask);
+        lds_at<int>(q.selw1)[1] = __popc((uint32_t)(bq1 >> sm.gsh) & fmask);
+    }
+    wave_lds_fence();
+    const uint64_t r = *lds_at<uint64_t>(q.selr);
+    act_v = (int)(int16_t)(uint32_t)r;              // 0xffff -> -1
+    cost_v = (int)(((uint32_t)r) >> 16);
+    quirk_cnt = (int)(r >> 32);
+    wave_lds_fence();
+}
+
 __device__ __forceinline__ int hbcast(int v, int src_local, bool upper) {   // v of local lane src_local of my half
     const int lo = rdlane(v, src_local), hi = rdlane(v, 32 + src_local);
     return upper ? hi : lo;
@@ -1107,31 +1200,6 @@ __device__ __forceinline__ int hbcast(int v, int src_local, bool upper) {   // v
 __device__ __forceinline__ bool hany(bool pred, bool upper) {               // pred on any lane of my half
     const uint64_t bm = __ballot(pred);
     return (upper ? (uint32_t)(bm >> 32) : (uint32_t)bm) != 0u;
-}
-
-// Mask algebra for paired waves: predicates that are uniform per half are kept as 64-bit lane masks in
-// SGPRs and combined with scalar instructions; only the primitive compares are vector work.
-__device__ __forceinline__ uint64_t bal(bool p) { return __builtin_amdgcn_ballot_w64(p); }
-__device__ __forceinline__ bool lanes(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
-static constexpr uint64_t kLowHalf = 0x00000000ffffffffull, kHighHalf = 0xffffffff00000000ull;
-__device__ __forceinline__ uint64_t half_any(uint64_t m) {      // each half all-ones iff any of its bits is set
-    const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
-    const uint32_t mlo = lo ? ~0u : 0u, mhi = hi ? ~0u : 0u;
-    return ((uint64_t)mhi << 32) | mlo;
-}
-__device__ __forceinline__ uint64_t half_pick(uint64_t lo_src, uint64_t hi_src) {
-    return (lo_src & kLowHalf) | (hi_src & kHighHalf);
-}
-// lane i <- lane i - D inside its row of 16 (agents of a half sit on lanes 0..7 of a row); zero fill
-template <int D>
-__device__ __forceinline__ int dpp_shr(int v) {
-    return __builtin_amdgcn_update_dpp(0, v, 0x110 + D, 0xf, 0xf, true);
-}
-// Police pairs (k - D, k): does either one target the other's node or the same node?  Evaluated on lane k.
-template <int D>
-__device__ __forceinline__ uint64_t pair_conflicts(int tgt_v, int pos_v) {
-    const int st = dpp_shr<D>(tgt_v), sp = dpp_shr<D>(pos_v);
-    return bal(tgt_v == st) | bal(tgt_v == sp) | bal(pos_v == st);
 }
 
 // sample_starts for both halves at once (values replicated per half instead of wave-uniform)
@@ -1307,16 +1375,26 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         const uint32_t m = c & 3u;
         return m == 0 ? xw[0] : (m == 1 ? xw[1] : (m == 2 ? xw[2] : xw[3]));
     };
-    wave_lds_fence();
-    int qcnt = 0, act_v = -1, cost_v = 0;
-    scan_sample_pair(L.ell_s, E.mrow, E1.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, draw_word(sc_v), act_v, cost_v,
-                     qcnt);
-
     const int RW = p.rec_words;
     const size_t BA = (size_t)B * A;
     if (a0 < 32) rec_h[a0 + 32 * 0] = 0;
     rec_h[32 + a0] = 0;                              // padding words of the record row stay zero
     wave_lds_fence();
+    int qcnt = 0, act_v = -1, cost_v = 0;
+    const bool one_pass = A <= sm.per_pass;          // wave-uniform: every agent scanned in a single pass
+    PairScanLane psl = make_pair_scan_lane(E, E1, sm, lane, A, NS);
+    if (one_pass) {
+        for (int i = lane; i < n16; i += kWave) {
+            reinterpret_cast<uint4*>(E.mrow)[i] = make_uint4(0, 0, 0, 0);
+            reinterpret_cast<uint4*>(E1.mrow)[i] = make_uint4(0, 0, 0, 0);
+        }
+        wave_lds_fence();
+        const ScanPairIn g0 = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, draw_word(sc_v));
+        scan_eval_pair1(psl, sm, p.scan_w, g0, act_v, cost_v, qcnt);
+    } else {
+        scan_sample_pair(L.ell_s, E.mrow, E1.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, draw_word(sc_v), act_v,
+                         cost_v, qcnt);
+    }
     double rew = 0.0;
     int term_v = 0, trunc_v = 0, win_v = 0;
     const uint64_t POLM = (((1ull << P) - 1ull) << 1) * 0x0000000100000001ull;   // police lanes of both halves
@@ -1411,7 +1489,8 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         SY_STAMP(3)
         // ---- F. evaluate half of the post-move scan: masks, position-reward counts, next action
         int act_n = -1, cost_n = 0;
-        scan_eval_pair(L.ell_s, E.mrow, E1.mrow, ln, A, NS, n16, p.scan_w, sm, sg, pos_v, mon_v, x_next, act_n, cost_n, qcnt);
+        if (one_pass) scan_eval_pair1(psl, sm, p.scan_w, sg, act_n, cost_n, qcnt);
+        else scan_eval_pair(L.ell_s, E.mrow, E1.mrow, ln, A, NS, n16, p.scan_w, sm, sg, pos_v, mon_v, x_next, act_n, cost_n, qcnt);
         SY_STAMP(4)
 
         // ---- D. outcome priority (reward_calculator.py:63-90) and rewards
@@ -1456,8 +1535,13 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
                 flags_v = 1;
             }
             wave_lds_fence();
-            if (rdlane((int)need, 0)) scan_sample(L.ell_s, E.mrow, ln, A, NS, n16, p.scan_w, sm, pos_v, mon_v, x_next, act_n, cost_n, qcnt, 0);
-            if (rdlane((int)need, 32)) scan_sample(L.ell_s, E1.mrow, ln, A, NS, n16, p.scan_w, sm, pos_v, mon_v, x_next, act_n, cost_n, qcnt, 32);
+            if (one_pass) {   // both halves rescanned: the untouched one reproduces its result
+                const ScanPairIn g2 = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, x_next);
+                scan_eval_pair1(psl, sm, p.scan_w, g2, act_n, cost_n, qcnt);
+            } else {
+                if (rdlane((int)need, 0)) scan_sample(L.ell_s, E.mrow, ln, A, NS, n16, p.scan_w, sm, pos_v, mon_v, x_next, act_n, cost_n, qcnt, 0);
+                if (rdlane((int)need, 32)) scan_sample(L.ell_s, E1.mrow, ln, A, NS, n16, p.scan_w, sm, pos_v, mon_v, x_next, act_n, cost_n, qcnt, 32);
+            }
         }
         if (!need && p.reveal_k > 0) {
             rev_v -= 1;

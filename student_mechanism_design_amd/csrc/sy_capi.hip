@@ -77,7 +77,7 @@ int sy_env_create(const sy_env_config* c, sy_env** out) {
     p.rec_words = sy_record_words(p.A);
     p.scan_w = 16;
     // per-block LDS: board ELL (64 B/node) + belief gather offsets (32 B/node) + reward tables
-    const size_t ell_bytes = (size_t)p.N * SY_ELL_WIDTH * 6 + (size_t)(3 * SY_LDS_TABLE + 2 + SY_LDS_AVGTAB + 16) * sizeof(double);
+    const size_t ell_bytes = (size_t)p.N * SY_ELL_WIDTH * 6 + (size_t)(4 * SY_LDS_TABLE + 4 + SY_LDS_AVGTAB + 16) * sizeof(double);
     // with a belief every episode runs two waves (move + belief), so a 1024-thread block holds 8 episodes
     int wpb = c->waves_per_block ? c->waves_per_block : 8;
     if (wpb > 8) wpb = 8;

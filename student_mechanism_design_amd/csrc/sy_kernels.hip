@@ -410,6 +410,7 @@ struct RewardTabs {
     const double* cov_s;   // [kLdsTab]     exp(-log1p(v))
     const double* nrc_s;   // [kLdsTab]     -1/(d+1)
     const double* nra_s;   // [kAvgTab]     -1/(s/P+1)
+    const double* px_s;    // [kLdsTab + 1] exp(-d) for d > 1, else 0.0 (the proximity term's filter folded into the table)
     const double* exp_g;   // global tables (any length)
     const double* cov_g;
     int n_exp, n_cov;
@@ -632,7 +633,7 @@ __device__ __forceinline__ const T* at_bytes(const T* base, uint32_t byte_off) {
 struct LdsMap {
     uint32_t* ell_s;
     uint16_t* boff_s;
-    double *exp_s, *cov_s, *nrc_s, *nra_s, *kc_s;
+    double *exp_s, *cov_s, *nrc_s, *nra_s, *px_s, *kc_s;
     unsigned char* env_base;   // first per-episode slice
 };
 __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, int N) {
@@ -642,7 +643,8 @@ __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, int N) {
     m.cov_s = m.exp_s + (kLdsTab + 2);
     m.nrc_s = m.cov_s + kLdsTab;
     m.nra_s = m.nrc_s + kLdsTab;
-    m.kc_s = m.nra_s + kAvgTab;
+    m.px_s = m.nra_s + kAvgTab;
+    m.kc_s = m.px_s + (kLdsTab + 2);
     m.ell_s = reinterpret_cast<uint32_t*>(m.kc_s + 16);
     m.boff_s = reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(m.ell_s) + (size_t)N * kD * 4);
     m.env_base = reinterpret_cast<unsigned char*>(m.ell_s) + (size_t)N * kD * 6;
@@ -702,8 +704,9 @@ __device__ __forceinline__ void stage_block(const EngineParams& p, const LdsMap&
             L.exp_s[i] = i < p.n_exp ? p.exp_tab[i] : 0.0;
             L.cov_s[i] = p.cov_tab[i < p.n_cov ? i : p.n_cov - 1];
             L.nrc_s[i] = -1.0 / ((double)i + 1.0);
+            L.px_s[i] = (i > 1 && i < p.n_exp) ? p.exp_tab[i] : 0.0;
         }
-        if (threadIdx.x == 0) L.exp_s[kLdsTab] = 0.0;
+        if (threadIdx.x == 0) { L.exp_s[kLdsTab] = 0.0; L.px_s[kLdsTab] = 0.0; }
         for (int i = threadIdx.x; i < kAvgTab; i += blockDim.x) L.nra_s[i] = -1.0 / ((double)i / (double)p.P + 1.0);
         if (threadIdx.x < 2) {
             double kc[8];
@@ -1292,6 +1295,71 @@ __device__ __forceinline__ double shaped_reward2(const RewardTabs& tb, int a, bo
     return a == 0 ? base : pol;
 }
 
+// shaped_reward2 with the vector work trimmed: min / sum of the police-to-MrX distances by DPP
+// butterflies over the 8 agent lanes of a row, the proximity filter (d > 1) folded into a second
+// table, MrX's / police terms selected once at the end.
+template <int CTRL>
+__device__ __forceinline__ int dpp_perm(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ double shaped_reward3(const RewardTabs& tb, int a, int P, uint64_t POLM, int t_v, int qcnt, int vc,
+                                                 int dm, const int (&dj)[SY_MAX_AGENTS - 1], const Coefs<true>& kc) {
+    int mn = lanes(POLM) ? dm : 0x7fffffff, sum = dm;        // dm is 0 off the police lanes
+    { const int o = dpp_perm<0xB1>(mn); mn = o < mn ? o : mn; }   // lane ^ 1
+    sum += dpp_perm<0xB1>(sum);
+    { const int o = dpp_perm<0x4E>(mn); mn = o < mn ? o : mn; }   // lane ^ 2
+    sum += dpp_perm<0x4E>(sum);
+    { const int o = dpp_perm<0x141>(mn); mn = o < mn ? o : mn; }  // lane -> 7 - lane (the other quad)
+    sum += dpp_perm<0x141>(sum);
+    int dor = dm | (vc < kLdsTab ? 0 : kLdsTab) | (sum < kAvgTab ? 0 : kLdsTab);   // mn <= dm-values <= sum
+#pragma unroll
+    for (int j = 1; j < SY_MAX_AGENTS; ++j) dor |= dj[j - 1];
+    double xa, xb, group = 0.0, prox = 0.0, e_mrx, cov;
+    int overlap = 0;
+    if (bal(dor >= kLdsTab) == 0ull) {
+        // fast path (wave-uniform): every lookup hits the LDS tables, all reads issued back to back
+        xa = lds_f64(tb.nrc_s + mn);     // lanes past the agents read out of range: LDS returns garbage or 0, unused
+        xb = lds_f64(tb.nra_s + sum);
+        e_mrx = lds_f64(tb.exp_s + dm);
+        cov = lds_f64(tb.cov_s + vc);
+        double ex[SY_MAX_AGENTS - 1], px[SY_MAX_AGENTS - 1];
+        int idx[SY_MAX_AGENTS - 1];
+#pragma unroll
+        for (int j = 1; j < SY_MAX_AGENTS; ++j) {
+            idx[j - 1] = j != a ? dj[j - 1] : kLdsTab;                  // own slot reads the 0.0 entries
+            ex[j - 1] = j <= P ? lds_f64(tb.exp_s + idx[j - 1]) : 0.0;
+            px[j - 1] = j <= P ? lds_f64(tb.px_s + idx[j - 1]) : 0.0;
+        }
+#pragma unroll
+        for (int j = 1; j < SY_MAX_AGENTS; ++j) {
+            if (j <= P) {
+                group += ex[j - 1];                                  // x + 0.0 == x
+                prox += px[j - 1];
+                overlap += idx[j - 1] <= 1 ? 1 : 0;
+            }
+        }
+    } else {
+        xa = -1.0 / ((double)mn + 1.0);
+        xb = -1.0 / ((double)sum / (double)P + 1.0);
+#pragma unroll
+        for (int j = 1; j < SY_MAX_AGENTS; ++j) {
+            if (j <= P) {
+                const int dij = dj[j - 1];
+                const bool other = j != a;
+                const double ex = other ? exp_neg_slow(tb, dij) : 0.0;
+                group += ex;
+                prox += dij > 1 ? ex : 0.0;
+                overlap += (other && dij <= 1) ? 1 : 0;
+            }
+        }
+        e_mrx = exp_neg_slow(tb, dm);
+        cov = tb.cov_g[vc < tb.n_cov ? vc : tb.n_cov - 1];
+    }
+    const double ts = (double)t_v;
+    const double x0 = a == 0 ? xa : e_mrx, x1 = a == 0 ? xb : group;
+    const double base = ((kc.get(0) * x0 + kc.get(1) * x1) + kc.get(2) * (double)qcnt) + kc.get(3) * (kc.get(7) * ts);
+    const double pol = ((base + kc.get(4) * prox) - kc.get(5) * (double)overlap) + kc.get(6) * cov;
+    return a == 0 ? base : pol;
+}
+
 // Diagnostic phase timers (-DSY_STAMPS builds only; each stamp drains the LDS queue, so the build is
 // for attribution, not for benchmarking).
 #ifdef SY_STAMPS
@@ -1352,7 +1420,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
     Coefs<true> kc;
     kc.s = L.kc_s + (a0 == 0 ? 0 : 8);
     RewardTabs tb;
-    tb.exp_s = L.exp_s; tb.cov_s = L.cov_s; tb.nrc_s = L.nrc_s; tb.nra_s = L.nra_s;
+    tb.exp_s = L.exp_s; tb.cov_s = L.cov_s; tb.nrc_s = L.nrc_s; tb.nra_s = L.nra_s; tb.px_s = L.px_s;
     tb.exp_g = p.exp_tab; tb.cov_g = p.cov_tab; tb.n_exp = p.n_exp; tb.n_cov = p.n_cov;
     // per-lane views of the half's LDS slice
     uint16_t* const vis_h = upper0 ? E1.vis_s : E.vis_s;
@@ -1360,6 +1428,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
     int* const ring_h = upper0 ? E1.ring : E.ring;
     int* const sync_h = upper0 ? E1.sync : E.sync;
     uint8_t* const mrow_h = upper0 ? E1.mrow : E.mrow;
+    const uint32_t ring_off = lds_off(ring_h);
 
     // ---- load both episodes' state
     int pos_v = a0 < A ? p.st.pos[(size_t)eh * A + a0] : 0;
@@ -1457,7 +1526,15 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         if (is_pol) {                                                         // :244-245
             vc = (int)atomicAdd(vis32 + pos_v, 1u) + 1;
         }
-        const int mrx_v = hbcast(pos_v, 0, upper);
+        // every agent's node to every lane of its half through the ring slot this step will publish
+        // (one LDS round trip instead of P + 1 lane broadcasts)
+        const uint32_t slot_off = ring_off + (uint32_t)(s & (kRing - 1)) * 32u;
+        if (lanes(kAgentSlots)) lds_at<int>(slot_off)[a] = a <= P ? pos_v : -1;
+        wave_lds_fence();
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        const v4i qa = *lds_at<v4i>(slot_off), qb = *lds_at<v4i>(slot_off + 16u);
+        const int q[SY_MAX_AGENTS] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        const int mrx_v = q[0];
         const uint32_t rowb = (uint32_t)(pos_v * N) * 2u;
         int dm = 0;
         int dj[SY_MAX_AGENTS - 1];
@@ -1467,7 +1544,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
             dm = (int)*at_bytes(ap, rowb + (uint32_t)mrx_v * 2u);
 #pragma unroll
             for (int j = 1; j < SY_MAX_AGENTS; ++j)
-                if (j <= P) dj[j - 1] = (int)*at_bytes(ap, rowb + (uint32_t)hbcast(pos_v, j, upper) * 2u);
+                if (j <= P) dj[j - 1] = (int)*at_bytes(ap, rowb + (uint32_t)q[j] * 2u);
         }
 
         SY_STAMP(2)
@@ -1494,14 +1571,14 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         SY_STAMP(4)
 
         // ---- D. outcome priority (reward_calculator.py:63-90) and rewards
-        const bool captured = hany(is_pol && pos_v == mrx_v, upper);
+        const bool captured = lanes(half_any(bal(pos_v == mrx_v) & POLM));
         const bool timeout = t_v > p.max_t;
         term_v = (captured || (!timeout && no_money)) ? 1 : 0;
         trunc_v = (!captured && timeout) ? 1 : 0;
         win_v = captured ? 1 : ((timeout || no_money) ? 2 : 0);
         const bool ended = (term_v | trunc_v) != 0;
         int recw0 = 0, recw1 = 0;
-        const double shaped = shaped_reward2(tb, a, upper, P, is_pol, t_v, qcnt, vc, dm, dj, kc);
+        const double shaped = shaped_reward3(tb, a, P, POLM, t_v, qcnt, vc, dm, dj, kc);
         rew = ended ? (captured ? (a == 0 ? -1.0 : 1.0) : (a == 0 ? 1.0 : 0.0)) : shaped;
         t_v += 1;   // yard.py:355
         sc_v += 1u;

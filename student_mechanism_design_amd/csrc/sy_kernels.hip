@@ -1234,6 +1234,40 @@ __device__ __noinline__ int sample_starts2(int a, bool upper, int A, int N, uint
     return mine;
 }
 
+// sample_starts for the halves named in `need` (bit 0 / bit 32): the draws are vector work (one Philox
+// block per agent lane), the without-replacement bookkeeping runs on the scalar unit — its values
+// are uniform per half — and the results are dropped onto the agent lanes one by one.
+__device__ __forceinline__ int sample_starts_pair(uint64_t need, int ln, int a, int A, int N, uint64_t gid, uint32_t ctr,
+                                               uint32_t k0, uint32_t k1) {
+    uint32_t o[4];
+    philox4(gid, ctr, kPurposeReset, (uint32_t)a, k0, k1, o);
+    const int xv = (int)o[0];
+    int st = 0;
+    for (int h = 0; h < 2; ++h) {
+        if (((need >> (32 * h)) & 1ull) == 0ull) continue;
+        int sorted[SY_MAX_AGENTS];
+#pragma unroll
+        for (int j = 0; j < SY_MAX_AGENTS; ++j) sorted[j] = 0x7fffffff;
+#pragma unroll
+        for (int i = 0; i < SY_MAX_AGENTS; ++i) {
+            if (i < A) {
+                const uint32_t x = (uint32_t)rdlane(xv, 32 * h + i);
+                int r = (int)__umulhi(x, (uint32_t)(N - i));
+#pragma unroll
+                for (int j = 0; j < SY_MAX_AGENTS; ++j)
+                    if (j < i) r += (r >= sorted[j]) ? 1 : 0;
+#pragma unroll
+                for (int j = SY_MAX_AGENTS - 1; j >= 0; --j) {
+                    const int prev = j == 0 ? -1 : sorted[j - 1];
+                    sorted[j] = sorted[j] < r ? sorted[j] : (prev < r ? r : prev);
+                }
+                st = ln == 32 * h + i ? r : st;
+            }
+        }
+    }
+    return st;
+}
+
 // shaped_reward for a paired wave: mn / sum are per-half vectors (reward_calculator.py:94-266)
 __device__ __forceinline__ double shaped_reward2(const RewardTabs& tb, int a, bool upper, int P, bool is_pol, int t_v,
                                                  int qcnt, int vc, int dm, const int (&dj)[SY_MAX_AGENTS - 1],
@@ -1428,7 +1462,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
     int* const ring_h = upper0 ? E1.ring : E.ring;
     int* const sync_h = upper0 ? E1.sync : E.sync;
     uint8_t* const mrow_h = upper0 ? E1.mrow : E.mrow;
-    const uint32_t ring_off = lds_off(ring_h);
+    const uint32_t xch_off = lds_off(rec_h) + kSelWord * 4u;   // 8 words: agent positions exchanged inside a step
 
     // ---- load both episodes' state
     int pos_v = a0 < A ? p.st.pos[(size_t)eh * A + a0] : 0;
@@ -1510,38 +1544,53 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
                 }
             }
         }
-        const bool no_money = lanes(~half_any(POLM & ~SK));                   // :191,216
+        const uint64_t NM = ~half_any(POLM & ~SK);                            // nobody could act (:191,216)
+        // ---- outcome priority (reward_calculator.py:63-90): known as soon as the moves are
+        const uint64_t CAP = half_any(half_pick(bal(pos_v == rdlane(pos_v, 0)), bal(pos_v == rdlane(pos_v, 32))) & POLM);
+        const uint64_t TO = bal(t_v > p.max_t);                               // t_v is replicated over its half
+        const uint64_t ENDED = CAP | TO | NM;
+        const uint64_t NEED = p.auto_reset != 0 ? ENDED : 0ull;
+        term_v = lanes(CAP | (NM & ~TO)) ? 1 : 0;
+        trunc_v = lanes(TO & ~CAP) ? 1 : 0;
+        win_v = lanes(CAP) ? 1 : (lanes(TO | NM) ? 2 : 0);
+        // ---- the state the next step starts from: a finished episode restarts right here, so the one
+        // scan below already serves the new episode (its masks, its first action)
+        int pos_n = pos_v, mon_n = mon_v;
+        if (NEED != 0ull) {
+            const int st = sample_starts_pair(NEED, ln, a, A, N, gid, sc_v + 1u, p.seed_lo, p.seed_hi);
+            const int m_init = a == 0 ? SY_MRX_MONEY : (a < A ? p.money0 : 0);     // yard.py:117-119
+            pos_n = lanes(NEED) ? st : pos_v;
+            mon_n = lanes(NEED) ? m_init : mon_v;
+        }
         SY_STAMP(0)
-        // next step's draw + the gather half of the post-move scan, issued now (see scan_gather_pair)
+        // next step's draw + the gather half of the scan, issued now (see scan_gather_pair)
         const uint32_t nxt_v = sc_v + 1u;
-        if (__ballot((nxt_v & 3u) == 0u) != 0ull) {
+        if (bal((nxt_v & 3u) == 0u) != 0ull) {
             uint32_t nw[4];
             philox4(gid, nxt_v >> 2, kPurposeAct, (uint32_t)a, p.seed_lo, p.seed_hi, nw);
             if ((nxt_v & 3u) == 0u) { xw[0] = nw[0]; xw[1] = nw[1]; xw[2] = nw[2]; xw[3] = nw[3]; }
         }
         const uint32_t x_next = draw_word(nxt_v);
-        const ScanPairIn sg = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, x_next);
+        const ScanPairIn sg = scan_gather_pair(L.ell_s, A, sm, 0, pos_n, mon_n, x_next);
         SY_STAMP(1)
         int vc = 0;
         if (is_pol) {                                                         // :244-245
             vc = (int)atomicAdd(vis32 + pos_v, 1u) + 1;
         }
-        // every agent's node to every lane of its half through the ring slot this step will publish
-        // (one LDS round trip instead of P + 1 lane broadcasts)
-        const uint32_t slot_off = ring_off + (uint32_t)(s & (kRing - 1)) * 32u;
-        if (lanes(kAgentSlots)) lds_at<int>(slot_off)[a] = a <= P ? pos_v : -1;
+        // every agent's node to every lane of its half through LDS (the result-slot words of the record
+        // staging row, free until the scan is evaluated): one round trip instead of P + 1 lane broadcasts
+        if (lanes(kAgentSlots)) lds_at<int>(xch_off)[a] = pos_v;
         wave_lds_fence();
         typedef int v4i __attribute__((ext_vector_type(4)));
-        const v4i qa = *lds_at<v4i>(slot_off), qb = *lds_at<v4i>(slot_off + 16u);
+        const v4i qa = *lds_at<v4i>(xch_off), qb = *lds_at<v4i>(xch_off + 16u);
         const int q[SY_MAX_AGENTS] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-        const int mrx_v = q[0];
         const uint32_t rowb = (uint32_t)(pos_v * N) * 2u;
         int dm = 0;
         int dj[SY_MAX_AGENTS - 1];
 #pragma unroll
         for (int j = 1; j < SY_MAX_AGENTS; ++j) dj[j - 1] = 0;
         if (is_pol) {
-            dm = (int)*at_bytes(ap, rowb + (uint32_t)mrx_v * 2u);
+            dm = (int)*at_bytes(ap, rowb + (uint32_t)q[0] * 2u);
 #pragma unroll
             for (int j = 1; j < SY_MAX_AGENTS; ++j)
                 if (j <= P) dj[j - 1] = (int)*at_bytes(ap, rowb + (uint32_t)q[j] * 2u);
@@ -1564,23 +1613,18 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         }
 
         SY_STAMP(3)
-        // ---- F. evaluate half of the post-move scan: masks, position-reward counts, next action
+        // ---- F. evaluate half of the scan: masks, position-reward counts, next action
         int act_n = -1, cost_n = 0;
         if (one_pass) scan_eval_pair1(psl, sm, p.scan_w, sg, act_n, cost_n, qcnt);
-        else scan_eval_pair(L.ell_s, E.mrow, E1.mrow, ln, A, NS, n16, p.scan_w, sm, sg, pos_v, mon_v, x_next, act_n, cost_n, qcnt);
+        else scan_eval_pair(L.ell_s, E.mrow, E1.mrow, ln, A, NS, n16, p.scan_w, sm, sg, pos_n, mon_n, x_next, act_n, cost_n, qcnt);
         SY_STAMP(4)
 
-        // ---- D. outcome priority (reward_calculator.py:63-90) and rewards
-        const bool captured = lanes(half_any(bal(pos_v == mrx_v) & POLM));
-        const bool timeout = t_v > p.max_t;
-        term_v = (captured || (!timeout && no_money)) ? 1 : 0;
-        trunc_v = (!captured && timeout) ? 1 : 0;
-        win_v = captured ? 1 : ((timeout || no_money) ? 2 : 0);
-        const bool ended = (term_v | trunc_v) != 0;
+        // ---- D. rewards
         int recw0 = 0, recw1 = 0;
         const double shaped = shaped_reward3(tb, a, P, POLM, t_v, qcnt, vc, dm, dj, kc);
-        rew = ended ? (captured ? (a == 0 ? -1.0 : 1.0) : (a == 0 ? 1.0 : 0.0)) : shaped;
-        t_v += 1;   // yard.py:355
+        rew = lanes(ENDED) ? (lanes(CAP) ? (a == 0 ? -1.0 : 1.0) : (a == 0 ? 1.0 : 0.0)) : shaped;
+        const int t_rec = t_v;
+        t_v = lanes(NEED) ? 0 : t_v + 1;   // yard.py:355; a restarted episode begins at 0
         sc_v += 1u;
         SY_STAMP(5)
         if (REC) {
@@ -1591,36 +1635,23 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
                 rec_h[3 * A + a] = mon0_v;
                 rec_h[4 * A + a] = act_v;
             }
-            if (a < 4) rec_h[5 * A + a] = a == 0 ? t_v - 1 : (a == 1 ? term_v : (a == 2 ? trunc_v : win_v));
+            if (a < 4) rec_h[5 * A + a] = a == 0 ? t_rec : (a == 1 ? term_v : (a == 2 ? trunc_v : win_v));
             wave_lds_fence();
             recw0 = rec_h[a];            // the row leaves LDS now and HBM-bound at the end of the step,
-            recw1 = rec_h[a + 32];       // so its LDS round trip overlaps the reset / hand-off phase
+            recw1 = rec_h[a + 32];       // so its LDS round trip overlaps the hand-off phase
         }
 
         SY_STAMP(6)
-        // ---- E. next episode (auto-reset) and the hand-off to the belief wave
-        const bool need = ended && p.auto_reset != 0;
+        // ---- E. bookkeeping of a restart / reveal, and the hand-off to the belief wave
         int flags_v = 0;
-        if (__ballot(need) != 0ull) {
-            const int st = sample_starts2(a, upper, A, N, gid, sc_v, p.seed_lo, p.seed_hi);
-            if (need) {
-                pos_v = a < A ? st : 0;
-                mon_v = a == 0 ? SY_MRX_MONEY : (a < A ? p.money0 : 0);     // yard.py:117-119
-                t_v = 0;
+        if (NEED != 0ull) {
+            if (lanes(NEED)) {
                 rev_v = p.reveal_k;
                 for (int i = a; i < (NS >> 2); i += 32) reinterpret_cast<uint4*>(vis32)[i] = make_uint4(0, 0, 0, 0);
                 flags_v = 1;
             }
-            wave_lds_fence();
-            if (one_pass) {   // both halves rescanned: the untouched one reproduces its result
-                const ScanPairIn g2 = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, x_next);
-                scan_eval_pair1(psl, sm, p.scan_w, g2, act_n, cost_n, qcnt);
-            } else {
-                if (rdlane((int)need, 0)) scan_sample(L.ell_s, E.mrow, ln, A, NS, n16, p.scan_w, sm, pos_v, mon_v, x_next, act_n, cost_n, qcnt, 0);
-                if (rdlane((int)need, 32)) scan_sample(L.ell_s, E1.mrow, ln, A, NS, n16, p.scan_w, sm, pos_v, mon_v, x_next, act_n, cost_n, qcnt, 32);
-            }
         }
-        if (!need && p.reveal_k > 0) {
+        if (!lanes(NEED) && p.reveal_k > 0) {
             rev_v -= 1;
             if (rev_v == 0) {        // post-increment timestep is a multiple of reveal_k
                 rev_v = p.reveal_k;
@@ -1639,7 +1670,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
             }
             asm volatile("" ::: "memory");
             int* slot_p = ring_h + (s & (kRing - 1)) * 8;
-            if (a < 8) slot_p[a] = a == 0 ? (pos_v | (flags_v << 16)) : (a <= P ? pos_v : -1);
+            if (a < 8) slot_p[a] = a == 0 ? (pos_n | (flags_v << 16)) : (a <= P ? pos_n : -1);
             asm volatile("" ::: "memory");
             if (a == 0) lds_poke(sync_h, s + 1);
         }
@@ -1652,6 +1683,8 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
             out.record += (size_t)B * RW;
             if (out.mask) out.mask += BA * NS;
         }
+        pos_v = pos_n;
+        mon_v = mon_n;
         act_v = act_n;
         cost_v = cost_n;
         SY_STAMP(7)

@@ -46,6 +46,13 @@ __device__ __forceinline__ void wave_lds_fence() {
 __device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ int bperm(int byte_addr, int v) { return __builtin_amdgcn_ds_bpermute(byte_addr, v); }
 
+// Explicit LDS addressing: byte offsets in registers, typed address-space-3 accesses (always ds_* instructions).
+template <typename T>
+__device__ __forceinline__ __attribute__((address_space(3))) T* lds_at(uint32_t off) {   // LDS byte offset -> typed LDS pointer
+    return (__attribute__((address_space(3))) T*)(uintptr_t)off;
+}
+__device__ __forceinline__ uint32_t lds_off(const void* q) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)q; }
+
 // Mask algebra for paired waves: predicates that are uniform per half are kept as 64-bit lane masks in
 // SGPRs and combined with scalar instructions; only the primitive compares are vector work.
 __device__ __forceinline__ uint64_t bal(bool p) { return __builtin_amdgcn_ballot_w64(p); }
@@ -651,7 +658,7 @@ __device__ __forceinline__ LdsMap lds_map(unsigned char* smem, int N) {
     return m;
 }
 
-// Per-episode LDS slice: [sync 16 B][ring][record 256 B][belief scratch (NS+16)*4][visit counters NS*4][mask rows A*NS]
+// Per-episode LDS slice: [sync 16 B][ring][record 256 B][belief scratch (NS+16)*8][visit counters NS*4][mask rows A*NS]
 // — the fixed-size parts first, so they sit at immediate offsets from the slice base.
 struct EnvLds {
     uint8_t* mrow;
@@ -668,7 +675,7 @@ __device__ __forceinline__ EnvLds env_lds(unsigned char* base, int slot, int sli
     e.ring = e.sync + 4;
     e.rec_s = e.ring + kRing * 8;
     e.c_s = reinterpret_cast<float*>(e.rec_s + 64);
-    e.vis_s = reinterpret_cast<uint16_t*>(e.c_s + (NS + 16));
+    e.vis_s = reinterpret_cast<uint16_t*>(e.c_s + 2 * (NS + 16));   // 8 B per node: the paired kernel interleaves two episodes
     e.mrow = reinterpret_cast<uint8_t*>(e.vis_s + 2 * NS);   // NS*4 bytes: the paired kernel keeps 32-bit counters
     return e;
 }
@@ -687,16 +694,16 @@ __device__ __forceinline__ void load_coeffs(const EngineParams& p, int lane, dou
 
 // Stage the block's board: ELL rows (coalesced 16-byte loads), the belief gather offsets derived
 // from them, and (TABLES) the reward lookup tables.
-template <bool TABLES>
+template <bool TABLES, int CSHIFT = 2>
 __device__ __forceinline__ void stage_block(const EngineParams& p, const LdsMap& L, int g, int N) {
     const uint4* src = reinterpret_cast<const uint4*>(p.ell + (size_t)g * N * kD);
     uint4* dst = reinterpret_cast<uint4*>(L.ell_s);
     for (int i = threadIdx.x; i < N * 4; i += blockDim.x) {
         const uint4 v = src[i];
         dst[i] = v;
-        uint2 o;
-        o.x = ((v.x & 0xffffu) << 2) | ((v.y & 0xffffu) << 18);
-        o.y = ((v.z & 0xffffu) << 2) | ((v.w & 0xffffu) << 18);
+        uint2 o;   // byte offsets of the neighbours' belief-scratch entries (4 B each, 8 B in the paired kernel)
+        o.x = ((v.x & 0xffffu) << CSHIFT) | ((v.y & 0xffffu) << (16 + CSHIFT));
+        o.y = ((v.z & 0xffffu) << CSHIFT) | ((v.w & 0xffffu) << (16 + CSHIFT));
         reinterpret_cast<uint2*>(L.boff_s)[i] = o;
     }
     if (TABLES) {
@@ -1119,6 +1126,162 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
 }
 
 // ---------------------------------------------------------------------------------------------
+// Belief filter for the two episodes of a pair in lockstep (same board, same step): the scratch
+// holds both episodes' b / deg interleaved (8 B per node), so one 8-byte LDS gather serves both
+// and the sums are packed two-wide.  Per component the arithmetic and its order are exactly
+// belief_step's.
+// ---------------------------------------------------------------------------------------------
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <int NR>
+__device__ __forceinline__ void belief_step_pair(v2f (&b)[NR], const float (&ideg)[NR], const int (&slab_w)[NR],
+                                                 uint32_t c_off, const uint16_t* boff_s, int lane, int N, bool police_ev,
+                                                 const int (&pol0)[SY_MAX_AGENTS - 1], const int (&pol1)[SY_MAX_AGENTS - 1],
+                                                 int P) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = lane + 64 * r;
+        if (j < N) *lds_at<v2f>(c_off + (uint32_t)j * 8u) = b[r] * ideg[r];
+    }
+    if (lane == 0) *lds_at<v2f>(c_off + (uint32_t)N * 8u) = (v2f){0.0f, 0.0f};  // padding entries point here
+    wave_lds_fence();
+    auto ld = [c_off](uint32_t off) { return *lds_at<v2f>(c_off + off); };
+    constexpr int GR = NR < 2 ? NR : 2;     // slabs pipelined together (register budget: 8 two-wide gathers each)
+    v2f tot = {0.0f, 0.0f};
+#pragma unroll
+    for (int r0 = 0; r0 < NR; r0 += GR) {
+        uint4 o[GR];
+        int jr[GR];
+#pragma unroll
+        for (int q = 0; q < GR; ++q) {
+            const int j = lane + 64 * (r0 + q);
+            jr[q] = j < N ? j : N - 1;          // tail lanes read a valid row; their result is discarded
+            o[q] = r0 + q < NR ? *reinterpret_cast<const uint4*>(boff_s + (jr[q] << 4)) : make_uint4(0, 0, 0, 0);
+        }
+        v2f g[GR][8];
+#pragma unroll
+        for (int q = 0; q < GR; ++q) {
+            if (r0 + q < NR) {
+                g[q][0] = ld(o[q].x & 0xffffu); g[q][1] = ld(o[q].x >> 16);
+                g[q][2] = ld(o[q].y & 0xffffu); g[q][3] = ld(o[q].y >> 16);
+                g[q][4] = ld(o[q].z & 0xffffu); g[q][5] = ld(o[q].z >> 16);
+                g[q][6] = ld(o[q].w & 0xffffu); g[q][7] = ld(o[q].w >> 16);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < GR; ++q) {
+            const int r = r0 + q;
+            if (r < NR) {
+                const int j = lane + 64 * r;
+                v2f acc = ideg[r] == 0.0f ? b[r] : (v2f){0.0f, 0.0f};
+                acc += ((g[q][0] + g[q][1]) + (g[q][2] + g[q][3])) + ((g[q][4] + g[q][5]) + (g[q][6] + g[q][7]));
+                if (slab_w[r] > 2) {            // wave-uniform: some row of this slab has more than 8 neighbours
+                    const uint4 o2 = *reinterpret_cast<const uint4*>(boff_s + (jr[q] << 4) + 8);
+                    const v2f h0 = ld(o2.x & 0xffffu), h1 = ld(o2.x >> 16), h2 = ld(o2.y & 0xffffu), h3 = ld(o2.y >> 16);
+                    const v2f h4 = ld(o2.z & 0xffffu), h5 = ld(o2.z >> 16), h6 = ld(o2.w & 0xffffu), h7 = ld(o2.w >> 16);
+                    acc += ((h0 + h1) + (h2 + h3)) + ((h4 + h5) + (h6 + h7));
+                }
+                if (police_ev) {
+#pragma unroll
+                    for (int k = 0; k < SY_MAX_AGENTS - 1; ++k) {
+                        if (k < P && j == pol0[k]) acc.x = 0.0f;
+                        if (k < P && j == pol1[k]) acc.y = 0.0f;
+                    }
+                }
+                acc = j < N ? acc : (v2f){0.0f, 0.0f};
+                b[r] = acc;
+                tot += acc;
+            }
+        }
+    }
+    const float t0 = wave_sum(tot.x), t1 = wave_sum(tot.y);
+    const float uni = 1.0f / (float)N;
+    const float inv0 = t0 == 0.0f ? 0.0f : 1.0f / t0, inv1 = t1 == 0.0f ? 0.0f : 1.0f / t1;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = lane + 64 * r;
+        b[r].x = j < N ? (t0 == 0.0f ? uni : b[r].x * inv0) : 0.0f;
+        b[r].y = j < N ? (t1 == 0.0f ? uni : b[r].y * inv1) : 0.0f;
+    }
+    wave_lds_fence();
+}
+
+template <int NR, bool REC>
+__device__ __forceinline__ void belief_pair_run(const EngineParams& p, const LdsMap& L, const EnvLds& E, const EnvLds& E1,
+                                                int lane, int e, int g, int P, int T, sy_rollout_buffers out) {
+    const int N = p.N, NS = p.NS, B = p.B;
+    const bool live1 = e + 1 < B;
+    v2f b[NR];
+    float ideg[NR], b0[NR];
+    int slab_w[NR];
+    belief_load<NR>(b0, ideg, slab_w, p.st.belief + (size_t)e * NS, p.inv_deg + (size_t)g * NS, lane, N);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = lane + 64 * r;
+        b[r].x = b0[r];
+        b[r].y = (live1 && j < N) ? p.st.belief[(size_t)(e + 1) * NS + j] : 0.0f;
+    }
+    const uint32_t c_off = lds_off(E.c_s);
+    const uint32_t off_bel = ((uint32_t)e * (uint32_t)NS + (uint32_t)lane) * 4u;
+    const bool rec_bel = REC && out.belief != nullptr;
+    const bool onehot = p.belief_onehot != 0, pol_ev = p.police_ev != 0;
+    const float uni = 1.0f / (float)N;
+    for (int s = 0; s < T; ++s) {
+        if (rec_bel) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                if (lane + 64 * r < NS) {
+                    *at_bytes(out.belief, off_bel + 256u * r) = b[r].x;
+                    if (live1) *at_bytes(out.belief, off_bel + (uint32_t)NS * 4u + 256u * r) = b[r].y;
+                }
+            }
+        }
+        // both ring entries of step s are published by one instruction of the pair's move wave
+        for (int spin = 0; lds_peek(E.sync) <= s && spin < kSpinMax; ++spin) __builtin_amdgcn_s_sleep(2);
+        asm volatile("" ::: "memory");
+        const int so = (s & (kRing - 1)) * 8;
+        const int head0 = __builtin_amdgcn_readfirstlane(E.ring[so]), head1 = __builtin_amdgcn_readfirstlane(E1.ring[so]);
+        int pol0[SY_MAX_AGENTS - 1], pol1[SY_MAX_AGENTS - 1];
+#pragma unroll
+        for (int k = 0; k < SY_MAX_AGENTS - 1; ++k) pol0[k] = pol1[k] = -1;
+        if (pol_ev) {
+#pragma unroll
+            for (int k = 0; k < SY_MAX_AGENTS - 1; ++k) {
+                pol0[k] = __builtin_amdgcn_readfirstlane(E.ring[so + 1 + k]);
+                pol1[k] = __builtin_amdgcn_readfirstlane(E1.ring[so + 1 + k]);
+            }
+        }
+        asm volatile("" ::: "memory");
+        if (lane < 2) lds_poke(lane == 0 ? E.sync + 1 : E1.sync + 1, s + 1);   // entries copied: the slots may be reused
+        const int node0 = head0 & 0xffff, flags0 = head0 >> 16, node1 = head1 & 0xffff, flags1 = head1 >> 16;
+        v2f nb[NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) nb[r] = b[r];
+        if (((flags0 & 3) == 0) || ((flags1 & 3) == 0))
+            belief_step_pair<NR>(nb, ideg, slab_w, c_off, L.boff_s, lane, N, pol_ev, pol0, pol1, P);
+        // new episode -> prior, reveal -> delta, else the filtered belief; per episode
+        const bool d0 = (flags0 & 2) || ((flags0 & 1) && onehot), u0 = (flags0 & 1) && !onehot;
+        const bool d1 = (flags1 & 2) || ((flags1 & 1) && onehot), u1 = (flags1 & 1) && !onehot;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int j = lane + 64 * r;
+            const float in = j < N ? 1.0f : 0.0f;
+            b[r].x = d0 ? (j == node0 ? in : 0.0f) : (u0 ? uni * in : nb[r].x);
+            b[r].y = d1 ? (j == node1 ? in : 0.0f) : (u1 ? uni * in : nb[r].y);
+        }
+        if (rec_bel) out.belief += (size_t)B * NS;
+    }
+    float* bel_out = kernarg_params()->st.belief;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = lane + 64 * r;
+        if (j < NS) {
+            bel_out[(size_t)e * NS + j] = b[r].x;
+            if (live1) bel_out[(size_t)(e + 1) * NS + j] = b[r].y;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // rollout2_kernel: the fused rollout with PAIRED move waves.  Most of a step touches only the A <= 8
 // agent lanes, so one move wave carries two episodes: lanes 0-31 hold episode `e`, lanes 32-63 episode
 // `e + 1` (agent a on lane h*32 + a).  What was wave-uniform per episode (timestep, flags, MrX's node,
@@ -1139,11 +1302,6 @@ struct PairScanLane {        // per-lane constants (LDS byte offsets) + the two 
     uint32_t prev0, prev1;
     uint64_t on_m, lead_m;   // lanes scanning a real agent; the first lane of each such group
 };
-template <typename T>
-__device__ __forceinline__ __attribute__((address_space(3))) T* lds_at(uint32_t off) {   // LDS byte offset -> typed LDS pointer
-    return (__attribute__((address_space(3))) T*)(uintptr_t)off;
-}
-__device__ __forceinline__ uint32_t lds_off(const void* q) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)q; }
 static constexpr int kSelWord = 48, kDummyWord = 47;
 static constexpr uint64_t kAgentSlots = 0x000000ff000000ffull;   // lanes 0..7 of both halves
 
@@ -1427,7 +1585,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
     const EnvLds E = env_lds(L.env_base, slot, p.wave_lds_bytes, A, NS);
     int g = __builtin_amdgcn_readfirstlane(p.env_graph[e0 < B ? e0 : B - 1]);
     g = g < 0 ? 0 : (g >= p.G ? p.G - 1 : g);
-    stage_block<true>(p, L, g, N);
+    stage_block<true, 3>(p, L, g, N);
     const EnvLds E1 = env_lds(L.env_base, slot + 1, p.wave_lds_bytes, A, NS);
     if (!belief_role && lane == 0) {
         E.sync[0] = 0; E.sync[1] = 0;
@@ -1437,7 +1595,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
     if (e >= B) return;
     sy_rollout_buffers out = out_arg;
     if (belief_role) {
-        belief_wave_run<NR, REC>(p, L, E, lane, slot, e, g, wpb, P, A, T, out);
+        belief_pair_run<NR, REC>(p, L, E, E1, lane, e, g, P, T, out);
         return;
     }
 

@@ -571,7 +571,7 @@ __device__ __forceinline__ void belief_step(float (&b)[NR], const float (&ideg)[
     }
     tot = wave_sum(tot);
     const float uni = 1.0f / (float)N;
-    const float inv = tot == 0.0f ? 0.0f : 1.0f / tot;
+    const float inv = tot == 0.0f ? 0.0f : __builtin_amdgcn_rcpf(tot);   // 1 ulp; the filter's tolerance is 1e-5
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int j = lane + 64 * r;
@@ -1136,11 +1136,12 @@ template <int NR>
 __device__ __forceinline__ void belief_step_pair(v2f (&b)[NR], const float (&ideg)[NR], const int (&slab_w)[NR],
                                                  uint32_t c_off, const uint16_t* boff_s, int lane, int N, bool police_ev,
                                                  const int (&pol0)[SY_MAX_AGENTS - 1], const int (&pol1)[SY_MAX_AGENTS - 1],
-                                                 int P) {
+                                                 int P, float uni) {
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int j = lane + 64 * r;
-        if (j < N) *lds_at<v2f>(c_off + (uint32_t)j * 8u) = b[r] * ideg[r];
+        // slabs below N / 64 are full (a scalar test); NR may be rounded up past the last partial slab
+        if (r < (N >> 6) || j < N) *lds_at<v2f>(c_off + (uint32_t)j * 8u) = b[r] * ideg[r];
     }
     if (lane == 0) *lds_at<v2f>(c_off + (uint32_t)N * 8u) = (v2f){0.0f, 0.0f};  // padding entries point here
     wave_lds_fence();
@@ -1194,13 +1195,18 @@ __device__ __forceinline__ void belief_step_pair(v2f (&b)[NR], const float (&ide
         }
     }
     const float t0 = wave_sum(tot.x), t1 = wave_sum(tot.y);
-    const float uni = 1.0f / (float)N;
-    const float inv0 = t0 == 0.0f ? 0.0f : 1.0f / t0, inv1 = t1 == 0.0f ? 0.0f : 1.0f / t1;
+    // b * (1 / total), or the uniform distribution when the mass vanished: one fused multiply-add with
+    // per-episode uniform (scale, offset) = (1/t, 0) or (0, 1/N); x * s + 0 rounds exactly like x * s
+    const v2f scale = {t0 == 0.0f ? 0.0f : __builtin_amdgcn_rcpf(t0), t1 == 0.0f ? 0.0f : __builtin_amdgcn_rcpf(t1)};
+    const v2f offs = {t0 == 0.0f ? uni : 0.0f, t1 == 0.0f ? uni : 0.0f};
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        const int j = lane + 64 * r;
-        b[r].x = j < N ? (t0 == 0.0f ? uni : b[r].x * inv0) : 0.0f;
-        b[r].y = j < N ? (t1 == 0.0f ? uni : b[r].y * inv1) : 0.0f;
+        b[r] = __builtin_elementwise_fma(b[r], scale, offs);
+        if (r >= (N >> 6)) {    // wave-uniform: only slabs from N / 64 on have lanes past the last node
+            const bool in = lane + 64 * r < N;
+            b[r].x = in ? b[r].x : 0.0f;
+            b[r].y = in ? b[r].y : 0.0f;
+        }
     }
     wave_lds_fence();
 }
@@ -1227,11 +1233,13 @@ __device__ __forceinline__ void belief_pair_run(const EngineParams& p, const Lds
     const float uni = 1.0f / (float)N;
     for (int s = 0; s < T; ++s) {
         if (rec_bel) {
+            float* row0 = at_bytes(out.belief, off_bel);
+            float* row1 = row0 + NS;
 #pragma unroll
             for (int r = 0; r < NR; ++r) {
-                if (lane + 64 * r < NS) {
-                    *at_bytes(out.belief, off_bel + 256u * r) = b[r].x;
-                    if (live1) *at_bytes(out.belief, off_bel + (uint32_t)NS * 4u + 256u * r) = b[r].y;
+                if (r < (NS >> 6) || lane + 64 * r < NS) {  // slabs below NS / 64 are full (a scalar test)
+                    row0[64 * r] = b[r].x;
+                    if (live1) row1[64 * r] = b[r].y;
                 }
             }
         }
@@ -1253,20 +1261,24 @@ __device__ __forceinline__ void belief_pair_run(const EngineParams& p, const Lds
         asm volatile("" ::: "memory");
         if (lane < 2) lds_poke(lane == 0 ? E.sync + 1 : E1.sync + 1, s + 1);   // entries copied: the slots may be reused
         const int node0 = head0 & 0xffff, flags0 = head0 >> 16, node1 = head1 & 0xffff, flags1 = head1 >> 16;
-        v2f nb[NR];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) nb[r] = b[r];
+        // the filter runs in place for both; an episode that restarts or reveals is overwritten below
         if (((flags0 & 3) == 0) || ((flags1 & 3) == 0))
-            belief_step_pair<NR>(nb, ideg, slab_w, c_off, L.boff_s, lane, N, pol_ev, pol0, pol1, P);
-        // new episode -> prior, reveal -> delta, else the filtered belief; per episode
-        const bool d0 = (flags0 & 2) || ((flags0 & 1) && onehot), u0 = (flags0 & 1) && !onehot;
-        const bool d1 = (flags1 & 2) || ((flags1 & 1) && onehot), u1 = (flags1 & 1) && !onehot;
+            belief_step_pair<NR>(b, ideg, slab_w, c_off, L.boff_s, lane, N, pol_ev, pol0, pol1, P, uni);
+        if (flags0 & 3) {   // new episode -> prior, reveal -> delta (wave-uniform branches)
+            const bool delta = (flags0 & 2) || onehot;
 #pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int j = lane + 64 * r;
-            const float in = j < N ? 1.0f : 0.0f;
-            b[r].x = d0 ? (j == node0 ? in : 0.0f) : (u0 ? uni * in : nb[r].x);
-            b[r].y = d1 ? (j == node1 ? in : 0.0f) : (u1 ? uni * in : nb[r].y);
+            for (int r = 0; r < NR; ++r) {
+                const int j = lane + 64 * r;
+                b[r].x = j < N ? (delta ? (j == node0 ? 1.0f : 0.0f) : uni) : 0.0f;
+            }
+        }
+        if (flags1 & 3) {
+            const bool delta = (flags1 & 2) || onehot;
+#pragma unroll
+            for (int r = 0; r < NR; ++r) {
+                const int j = lane + 64 * r;
+                b[r].y = j < N ? (delta ? (j == node1 ? 1.0f : 0.0f) : uni) : 0.0f;
+            }
         }
         if (rec_bel) out.belief += (size_t)B * NS;
     }

@@ -2250,6 +2250,7 @@ static hipError_t launch_engine_nr(const EngineParams& p, const int32_t* actions
         switch (p.P) {   // the BASELINE.json police counts get fully unrolled instances
             case 2: SY_LAUNCH_ROLLOUT(2); break;
             case 4: SY_LAUNCH_ROLLOUT(4); break;
+            case 5: SY_LAUNCH_ROLLOUT(5); break;
             case 6: SY_LAUNCH_ROLLOUT(6); break;
             default: SY_LAUNCH_ROLLOUT(0); break;
         }

@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--police", type=int, default=4)
     ap.add_argument("--money", type=int, default=20)
     ap.add_argument("--graphs", type=int, default=8, help="boards in the pool")
-    ap.add_argument("--fused", type=int, default=128, help="env steps per launch (T)")
+    ap.add_argument("--fused", type=int, default=256, help="env steps per launch (T); 256 ~ the reference's 250-step episode cap")
     ap.add_argument("--reveal", type=int, default=5)
     ap.add_argument("--wpb", type=int, default=0, help="waves (envs) per launch block, 0 = engine default")
     ap.add_argument("--no-record", action="store_true", help="do not write the trajectory (diagnostic only)")

@@ -1570,6 +1570,11 @@ __device__ __forceinline__ double shaped_reward3(const RewardTabs& tb, int a, in
 #define SY_STAMP_DECL unsigned long long stamp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long stamp_t = __builtin_amdgcn_s_memtime();
 #define SY_STAMP(i) { const unsigned long long stamp_n = __builtin_amdgcn_s_memtime(); stamp_acc[i] += stamp_n - stamp_t; stamp_t = stamp_n; }
 #define SY_STAMP_DUMP(T) if (blockIdx.x == 7 && threadIdx.x == 0) printf("stamps/step: C %llu G %llu V %llu B %llu F %llu D %llu R %llu E %llu S %llu\n", stamp_acc[0] / T, stamp_acc[1] / T, stamp_acc[2] / T, stamp_acc[3] / T, stamp_acc[4] / T, stamp_acc[5] / T, stamp_acc[6] / T, stamp_acc[7] / T, stamp_acc[8] / T);
+#elif defined(SY_ENDTIMES)   // load-balance builds: per move wave (start, end) on the constant 100 MHz clock, left in the
+                             // two padding words of the last record row (tools/endtimes.py reads them)
+#define SY_STAMP_DECL const unsigned long long wave_t0 = __builtin_amdgcn_s_memrealtime();
+#define SY_STAMP(i)
+#define SY_STAMP_DUMP(T) if (REC && a0 == 0 && store_ok) { int* lastrow = out.record - (size_t)B * RW + (size_t)eh * RW; lastrow[RW - 2] = (int)(unsigned)wave_t0; lastrow[RW - 1] = (int)(unsigned)__builtin_amdgcn_s_memrealtime(); }
 #elif defined(SY_PHASES)   // static census builds: tools/asm_phase_count.py reads the markers from the assembly
 #define SY_STAMP_DECL
 #define SY_STAMP(i) asm volatile("; ##PHASE P" #i);

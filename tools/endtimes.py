@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Launch-level load balance of the fused rollout: per move wave start / end times.
+
+Needs an engine built with -DSY_ENDTIMES (the kernel leaves both times, 100 MHz ticks, in the padding
+words of the last record row):
+    SY_HIPCC_FLAGS=-DSY_ENDTIMES python -m student_mechanism_design_amd.build   # or build to another path
+    SY_ENGINE_LIB=<that .so> python tools/endtimes.py [T]
+"""
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, '.')
+import student_mechanism_design_amd as sy  # noqa: E402
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+boards = sy.sample_board_pool(8, 200, 400, seed=0)
+env = sy.BatchedScotlandYardEnv(4096, boards, 4, 20, np.full(11, 0.5), seed=1234, reveal_interval=5)
+env.reset(seed=1)
+out = env.alloc_rollout(T)
+W = env.waves_per_block
+for it in range(3):
+    env.rollout(T, out=out)
+    torch.cuda.synchronize()
+    rec = out["record"][T - 1].cpu().numpy().astype(np.int64) & 0xffffffff   # [B, RW]
+    st, en = rec[:, -2], rec[:, -1]
+    t0 = st.min()
+    run = (en - st) / 100.0
+    end = (en - t0) / 100.0
+    print(f"T={T} launch {it}: wave run mean {run.mean():.1f} min {run.min():.1f} max {run.max():.1f} std {run.std():.1f} us")
+    print("    end percentiles 0/1/10/50/90/99/100:", np.percentile(end, [0, 1, 10, 50, 90, 99, 100]).round(1))
+    blk = end.reshape(-1, W).max(1)
+    print(f"    block end: mean {blk.mean():.1f} min {blk.min():.1f} max {blk.max():.1f}")
+    print("    mean end by move wave of the block:", end[0::2].reshape(-1, W // 2).mean(0).round(1))

@@ -1375,36 +1375,8 @@ __device__ __forceinline__ bool hany(bool pred, bool upper) {               // p
     return (upper ? (uint32_t)(bm >> 32) : (uint32_t)bm) != 0u;
 }
 
-// sample_starts for both halves at once (values replicated per half instead of wave-uniform)
-__device__ __noinline__ int sample_starts2(int a, bool upper, int A, int N, uint64_t gid, uint32_t ctr, uint32_t k0,
-                                           uint32_t k1) {
-    uint32_t o[4];
-    philox4(gid, ctr, kPurposeReset, (uint32_t)a, k0, k1, o);
-    const int xv = (int)o[0];
-    int sorted[SY_MAX_AGENTS];
-#pragma unroll
-    for (int j = 0; j < SY_MAX_AGENTS; ++j) sorted[j] = 0x7fffffff;
-    int mine = 0;
-#pragma unroll
-    for (int i = 0; i < SY_MAX_AGENTS; ++i) {
-        if (i < A) {
-            const uint32_t x = (uint32_t)hbcast(xv, i, upper);
-            int r = (int)__umulhi(x, (uint32_t)(N - i));
-#pragma unroll
-            for (int j = 0; j < SY_MAX_AGENTS; ++j)
-                if (j < i) r += (r >= sorted[j]) ? 1 : 0;
-#pragma unroll
-            for (int j = SY_MAX_AGENTS - 1; j >= 0; --j) {
-                const int prev = j == 0 ? -1 : sorted[j - 1];
-                sorted[j] = sorted[j] < r ? sorted[j] : (prev < r ? r : prev);
-            }
-            if (a == i) mine = r;
-        }
-    }
-    return mine;
-}
-
-// sample_starts for the halves named in `need` (bit 0 / bit 32): the draws are vector work (one Philox
+// sample_starts (distinct start nodes, see above) for the halves named in `need` (bit 0 / bit 32):
+// values are replicated per half instead of wave-uniform; the draws are vector work (one Philox
 // block per agent lane), the without-replacement bookkeeping runs on the scalar unit — its values
 // are uniform per half — and the results are dropped onto the agent lanes one by one.
 __device__ __forceinline__ int sample_starts_pair(uint64_t need, int ln, int a, int A, int N, uint64_t gid, uint32_t ctr,
@@ -1438,70 +1410,9 @@ __device__ __forceinline__ int sample_starts_pair(uint64_t need, int ln, int a, 
     return st;
 }
 
-// shaped_reward for a paired wave: mn / sum are per-half vectors (reward_calculator.py:94-266)
-__device__ __forceinline__ double shaped_reward2(const RewardTabs& tb, int a, bool upper, int P, bool is_pol, int t_v,
-                                                 int qcnt, int vc, int dm, const int (&dj)[SY_MAX_AGENTS - 1],
-                                                 const Coefs<true>& kc) {
-    int mn = 0x7fffffff, sum = 0;
-#pragma unroll
-    for (int k = 1; k < SY_MAX_AGENTS; ++k) {
-        if (k <= P) {
-            const int dk = hbcast(dm, k, upper);
-            mn = dk < mn ? dk : mn;
-            sum += dk;
-        }
-    }
-    int dor = dm | (vc < kLdsTab ? 0 : kLdsTab) | (sum < kAvgTab ? 0 : kLdsTab);   // mn <= dm-values <= sum
-#pragma unroll
-    for (int j = 1; j < SY_MAX_AGENTS; ++j) dor |= dj[j - 1];
-    double xa, xb, group = 0.0, prox = 0.0, e_mrx, cov;
-    int overlap = 0;
-    if (__ballot(dor >= kLdsTab) == 0ull) {
-        // fast path (wave-uniform): every lookup hits the LDS tables, all reads issued back to back
-        xa = lds_f64(tb.nrc_s + mn);
-        xb = lds_f64(tb.nra_s + sum);
-        e_mrx = lds_f64(tb.exp_s + dm);
-        cov = lds_f64(tb.cov_s + vc);
-        double ex[SY_MAX_AGENTS - 1];
-#pragma unroll
-        for (int j = 1; j < SY_MAX_AGENTS; ++j) ex[j - 1] = j <= P ? lds_f64(tb.exp_s + (j != a ? dj[j - 1] : kLdsTab)) : 0.0;
-#pragma unroll
-        for (int j = 1; j < SY_MAX_AGENTS; ++j) {
-            if (j <= P) {
-                const int dij = dj[j - 1];
-                group += ex[j - 1];                                  // slot kLdsTab = 0.0: x + 0.0 == x
-                prox += dij > 1 ? ex[j - 1] : 0.0;
-                overlap += (j != a && dij <= 1) ? 1 : 0;
-            }
-        }
-    } else {
-        xa = -1.0 / ((double)mn + 1.0);
-        xb = -1.0 / ((double)sum / (double)P + 1.0);
-#pragma unroll
-        for (int j = 1; j < SY_MAX_AGENTS; ++j) {
-            if (j <= P) {
-                const int dij = dj[j - 1];
-                const bool other = j != a;
-                const double ex = other ? exp_neg_slow(tb, dij) : 0.0;
-                group += ex;
-                prox += dij > 1 ? ex : 0.0;
-                overlap += (other && dij <= 1) ? 1 : 0;
-            }
-        }
-        e_mrx = exp_neg_slow(tb, dm);
-        cov = tb.cov_g[vc < tb.n_cov ? vc : tb.n_cov - 1];
-    }
-    const double ts = (double)t_v;
-    const double x0 = a == 0 ? xa : e_mrx, x1 = a == 0 ? xb : group;
-    const double base = ((kc.get(0) * x0 + kc.get(1) * x1) + kc.get(2) * (double)qcnt) + kc.get(3) * (kc.get(7) * ts);
-    const double pol = ((base + kc.get(4) * prox) - kc.get(5) * (double)overlap) + kc.get(6) * cov;
-    (void)is_pol;
-    return a == 0 ? base : pol;
-}
-
-// shaped_reward2 with the vector work trimmed: min / sum of the police-to-MrX distances by DPP
-// butterflies over the 8 agent lanes of a row, the proximity filter (d > 1) folded into a second
-// table, MrX's / police terms selected once at the end.
+// shaped_reward for a paired wave (reward_calculator.py:94-266): min / sum of the police-to-MrX
+// distances by DPP butterflies over the 8 agent lanes of a row, the proximity filter (d > 1) folded
+// into a second table, MrX's / police terms selected once at the end.
 template <int CTRL>
 __device__ __forceinline__ int dpp_perm(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
 __device__ __forceinline__ double shaped_reward3(const RewardTabs& tb, int a, int P, uint64_t POLM, int t_v, int qcnt, int vc,

@@ -119,7 +119,14 @@ int sy_env_set_graph_pool(sy_env* env, const uint32_t* ell, const uint16_t* apsp
     env->p.inv_deg = inv_deg;
     env->p.env_graph = env_graph;
     if (max_degree < 0 || max_degree > SY_ELL_WIDTH) return fail(SY_ERR_INVALID, "max_degree must be in [0, 16] (0 = unknown)%s");
-    env->p.scan_w = max_degree == 0 ? 16 : (max_degree <= 8 ? 8 : (max_degree <= 12 ? 12 : 16));
+    // ELL columns scanned per agent: 8, 12 or 16 (division-free lane mapping), or the pool's exact widest row
+    // when that lets more agents share a scan pass and they are needed (7 agents fit one pass up to rows of 9,
+    // 6 agents up to rows of 10); instances for at most 5 agents therefore only ever see 8 / 12 / 16
+    {
+        const int md = (max_degree <= 0 || max_degree > 16) ? 16 : (max_degree < 8 ? 8 : max_degree);
+        const int coarse = md <= 8 ? 8 : (md <= 12 ? 12 : 16);
+        env->p.scan_w = (env->p.A > 64 / coarse && 64 / md > 64 / coarse) ? md : coarse;
+    }
     env->has_graph = true;
     return SY_OK;
 }

@@ -143,8 +143,8 @@ __device__ __noinline__ int sample_starts(int lane, int A, int N, uint64_t gid, 
 }
 
 // Lane -> (agent slot, ELL column) mapping of the neighbour scans.  `gw` ELL columns per agent
-// (8, 12 or 16 — the host picks the smallest that covers the pool's widest row), so 8, 5 or 4
-// agents are scanned per pass: at P = 4 and rows of at most 12 neighbours one pass covers all 5.
+// (8..16: the pool's widest row, at least 8), so 64 / gw agents are scanned per pass: at P = 4 and
+// rows of at most 12 neighbours one pass covers all 5 agents, at P = 6 rows of at most 9 do.
 struct ScanMap {
     int grp, col, sh, per_pass;
     int gsh;            // bit offset of this lane's group inside a pass ballot
@@ -152,10 +152,16 @@ struct ScanMap {
     uint32_t lowmask;   // bits of the group's field below this lane's column
     bool live;
 };
+template <bool ANY_WIDTH = true>
 __device__ __forceinline__ ScanMap make_scan_map(int lane, int gw) {
     ScanMap m;
-    m.per_pass = gw == 8 ? 8 : (gw == 12 ? 5 : 4);
-    m.grp = gw == 8 ? (lane >> 3) : (gw == 12 ? (lane * 43) >> 9 : (lane >> 4));   // lane / gw for lane < 64
+    if (ANY_WIDTH) {     // any width in 8..16 (the host picks 9 or 10 when that saves a scan pass for 6 or 7 agents)
+        m.per_pass = 64 / gw;
+        m.grp = lane / gw;
+    } else {             // 8, 12 or 16: no division (instances for at most 5 agents never see another width)
+        m.per_pass = gw == 8 ? 8 : (gw == 12 ? 5 : 4);
+        m.grp = gw == 8 ? (lane >> 3) : (gw == 12 ? (lane * 43) >> 9 : (lane >> 4));
+    }
     m.col = lane - m.grp * gw;
     m.live = m.grp < m.per_pass;
     m.sh = (lane % m.per_pass) * gw;   // bit offset of agent (lane)'s field inside a pass ballot
@@ -1318,13 +1324,14 @@ static constexpr int kSelWord = 48, kDummyWord = 47;
 static constexpr uint64_t kAgentSlots = 0x000000ff000000ffull;   // lanes 0..7 of both halves
 
 __device__ __forceinline__ PairScanLane make_pair_scan_lane(const EnvLds& E, const EnvLds& E1, const ScanMap& sm, int lane,
-                                                            int A, int NS) {
+                                                            int A, int NS, int base = 0) {
     PairScanLane q;
-    const bool on = sm.live && sm.grp < A;
-    q.row0 = lds_off(E.mrow) + (uint32_t)(sm.grp * NS);
-    q.row1 = lds_off(E1.mrow) + (uint32_t)(sm.grp * NS);
-    q.selw0 = lds_off(E.rec_s) + (uint32_t)(kSelWord + 2 * (sm.grp & 7)) * 4u;
-    q.selw1 = lds_off(E1.rec_s) + (uint32_t)(kSelWord + 2 * (sm.grp & 7)) * 4u;
+    const int ag = base + sm.grp;              // the agent this lane's group scans in the pass starting at `base`
+    const bool on = sm.live && ag < A;
+    q.row0 = lds_off(E.mrow) + (uint32_t)(ag * NS);
+    q.row1 = lds_off(E1.mrow) + (uint32_t)(ag * NS);
+    q.selw0 = lds_off(E.rec_s) + (uint32_t)(kSelWord + 2 * (ag & 7)) * 4u;
+    q.selw1 = lds_off(E1.rec_s) + (uint32_t)(kSelWord + 2 * (ag & 7)) * 4u;
     const uint32_t rec_h = lane >= 32 ? lds_off(E1.rec_s) : lds_off(E.rec_s);
     q.selr = rec_h + (uint32_t)(kSelWord + 2 * (lane & 7)) * 4u;
     q.prev0 = lds_off(E.rec_s) + kDummyWord * 4u;
@@ -1334,9 +1341,12 @@ __device__ __forceinline__ PairScanLane make_pair_scan_lane(const EnvLds& E, con
     return q;
 }
 
+// BEGIN / END: the first pass of a step writes the "no move" defaults, the last one reads the slots back
+// (two passes when the agents do not fit one: e.g. P = 6 with rows wider than 9).
+template <bool BEGIN = true, bool END = true>
 __device__ __forceinline__ void scan_eval_pair1(PairScanLane& q, const ScanMap& sm, int gw, const ScanPairIn& g, int& act_v,
                                                 int& cost_v, int& quirk_cnt) {
-    if (lanes(kAgentSlots)) *lds_at<uint64_t>(q.selr) = 0x0000ffffull;   // "no move": action -1, cost 0
+    if (BEGIN && lanes(kAgentSlots)) *lds_at<uint64_t>(q.selr) = 0x0000ffffull;   // "no move": action -1, cost 0
     *lds_at<uint8_t>(q.prev0) = 0;
     *lds_at<uint8_t>(q.prev1) = 0;
     const uint32_t fmask = (1u << gw) - 1u;
@@ -1359,11 +1369,13 @@ __device__ __forceinline__ void scan_eval_pair1(PairScanLane& q, const ScanMap& 
         lds_at<int>(q.selw1)[1] = __popc((uint32_t)(bq1 >> sm.gsh) & fmask);
     }
     wave_lds_fence();
-    const uint64_t r = *lds_at<uint64_t>(q.selr);
-    act_v = (int)(int16_t)(uint32_t)r;              // 0xffff -> -1
-    cost_v = (int)(((uint32_t)r) >> 16);
-    quirk_cnt = (int)(r >> 32);
-    wave_lds_fence();
+    if (END) {
+        const uint64_t r = *lds_at<uint64_t>(q.selr);
+        act_v = (int)(int16_t)(uint32_t)r;              // 0xffff -> -1
+        cost_v = (int)(((uint32_t)r) >> 16);
+        quirk_cnt = (int)(r >> 32);
+        wave_lds_fence();
+    }
 }
 
 __device__ __forceinline__ int hbcast(int v, int src_local, bool upper) {   // v of local lane src_local of my half
@@ -1536,7 +1548,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
     const uint16_t* __restrict__ ap = p.apsp + (size_t)g * N * N;
     const uint64_t gid = p.env_id_offset + (uint64_t)eh;
     const int n16 = (A * NS) >> 4;
-    const ScanMap sm = make_scan_map(lane, p.scan_w);
+    const ScanMap sm = make_scan_map<(PT == 0 || PT >= 5)>(lane, p.scan_w);
     Coefs<true> kc;
     kc.s = L.kc_s + (a0 == 0 ? 0 : 8);
     RewardTabs tb;
@@ -1571,15 +1583,25 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
     wave_lds_fence();
     int qcnt = 0, act_v = -1, cost_v = 0;
     const bool one_pass = A <= sm.per_pass;          // wave-uniform: every agent scanned in a single pass
+    // two passes of the slot-based scan (instances that can have more than 5 agents only: registers)
+    const bool two_pass = (PT == 0 || PT >= 5) && !one_pass && A <= 2 * sm.per_pass;
     PairScanLane psl = make_pair_scan_lane(E, E1, sm, lane, A, NS);
-    if (one_pass) {
+    PairScanLane psl2 = psl;
+    if (two_pass) psl2 = make_pair_scan_lane(E, E1, sm, lane, A, NS, sm.per_pass);
+    if (one_pass || two_pass) {
         for (int i = lane; i < n16; i += kWave) {
             reinterpret_cast<uint4*>(E.mrow)[i] = make_uint4(0, 0, 0, 0);
             reinterpret_cast<uint4*>(E1.mrow)[i] = make_uint4(0, 0, 0, 0);
         }
         wave_lds_fence();
         const ScanPairIn g0 = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, draw_word(sc_v));
-        scan_eval_pair1(psl, sm, p.scan_w, g0, act_v, cost_v, qcnt);
+        if (one_pass) {
+            scan_eval_pair1(psl, sm, p.scan_w, g0, act_v, cost_v, qcnt);
+        } else {
+            const ScanPairIn g1 = scan_gather_pair(L.ell_s, A, sm, sm.per_pass, pos_v, mon_v, draw_word(sc_v));
+            scan_eval_pair1<true, false>(psl, sm, p.scan_w, g0, act_v, cost_v, qcnt);
+            scan_eval_pair1<false, true>(psl2, sm, p.scan_w, g1, act_v, cost_v, qcnt);
+        }
     } else {
         scan_sample_pair(L.ell_s, E.mrow, E1.mrow, lane, A, NS, n16, p.scan_w, sm, pos_v, mon_v, draw_word(sc_v), act_v,
                          cost_v, qcnt);
@@ -1658,6 +1680,8 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         }
         const uint32_t x_next = draw_word(nxt_v);
         const ScanPairIn sg = scan_gather_pair(L.ell_s, A, sm, 0, pos_n, mon_n, x_next);
+        ScanPairIn sg2 = sg;
+        if (two_pass) sg2 = scan_gather_pair(L.ell_s, A, sm, sm.per_pass, pos_n, mon_n, x_next);
         SY_STAMP(1)
         int vc = 0;
         if (is_pol) {                                                         // :244-245
@@ -1701,8 +1725,12 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         SY_STAMP(3)
         // ---- F. evaluate half of the scan: masks, position-reward counts, next action
         int act_n = -1, cost_n = 0;
-        if (one_pass) scan_eval_pair1(psl, sm, p.scan_w, sg, act_n, cost_n, qcnt);
-        else scan_eval_pair(L.ell_s, E.mrow, E1.mrow, ln, A, NS, n16, p.scan_w, sm, sg, pos_n, mon_n, x_next, act_n, cost_n, qcnt);
+        if (one_pass) {
+            scan_eval_pair1(psl, sm, p.scan_w, sg, act_n, cost_n, qcnt);
+        } else if (two_pass) {
+            scan_eval_pair1<true, false>(psl, sm, p.scan_w, sg, act_n, cost_n, qcnt);
+            scan_eval_pair1<false, true>(psl2, sm, p.scan_w, sg2, act_n, cost_n, qcnt);
+        } else scan_eval_pair(L.ell_s, E.mrow, E1.mrow, ln, A, NS, n16, p.scan_w, sm, sg, pos_n, mon_n, x_next, act_n, cost_n, qcnt);
         SY_STAMP(4)
 
         // ---- D. rewards

@@ -181,6 +181,42 @@ def test_fused_rollout_matches_oracle(sy, ol, cfg):
     env.close()
 
 
+def _hub_board(sy, n, hub_degree, rng):
+    """Ring of n nodes plus a hub (node 0) wired to `hub_degree` nodes in all: the pool's widest ELL row is exact."""
+    links = [(i, (i + 1) % n) for i in range(n)]
+    extra = rng.choice(np.arange(2, n - 1), size=hub_degree - 2, replace=False)
+    links += [(0, int(v)) for v in extra]
+    # a second, smaller hub so that wide rows are not a single-node affair
+    links += [(n // 2, int(v)) for v in rng.choice(np.setdiff1d(np.arange(2, n - 1), [n // 2 - 1, n // 2, n // 2 + 1]),
+                                                   size=max(hub_degree - 5, 1), replace=False)]
+    links = sorted({(min(a, b), max(a, b)) for a, b in links if a != b})
+    w = rng.integers(1, 5, size=len(links))
+    return sy.make_board(n, np.array(links, dtype=np.int32), w)
+
+
+@pytest.mark.parametrize("police,hub_degree", [(6, 9), (6, 10), (6, 12), (6, 16), (5, 10), (5, 12), (7, 9), (7, 14), (4, 13)])
+def test_fused_rollout_scan_widths_and_passes(sy, ol, police, hub_degree):
+    """Every lane mapping of the neighbour scan: exact widths 9 / 10 that save a pass for 6-7 agents, the
+    two-pass slot scan (7 agents at width 12, 6 at 12, 8 at 16), and the generic multi-pass fallback."""
+    rng = np.random.default_rng(1000 * police + hub_degree)
+    N, B, T = 48, 40, 60
+    boards = [_hub_board(sy, N, hub_degree, rng) for _ in range(2)]
+    weights = rng.uniform(0.05, 0.95, 11)
+    env = sy.BatchedScotlandYardEnv(B, boards, police, 9, weights, seed=77, reveal_interval=3)
+    assert env.max_degree == hub_degree
+    graphs = [ol.OracleGraph(N, b.edge_links, b.edges.astype(np.int32)) for b in boards]
+    orc = ol.OracleBatch(graphs, env.env_graph_host, B, police, 9, node_stride=env.NS, weights=weights,
+                         tables=sy.reward_tables(), reveal_interval=3)
+    orc.reset(seed=77)
+    rec = env.rollout(T)
+    ref = orc.rollout(T)
+    for k in ("pos", "t", "action", "terminated", "truncated", "winner", "mask", "reward"):
+        np.testing.assert_array_equal(_np(rec[k]), ref[k], err_msg=k)
+    np.testing.assert_allclose(_np(rec["belief"]), ref["belief"], rtol=0, atol=BELIEF_TOL)
+    _compare_state(env, orc, "after scan-width rollout")
+    env.close()
+
+
 def test_rollout_equals_stepping_its_own_actions(sy):
     """Fused sampling path == caller-action path: replaying the recorded actions through step()."""
     boards = sy.sample_board_pool(2, 60, 100, seed=21)

@@ -1318,6 +1318,7 @@ struct PairScanLane {        // per-lane constants (LDS byte offsets) + the two 
     uint32_t selw0, selw1;   // my group's slot, episode 0 / 1 (scan-lane role)
     uint32_t selr;           // slot of agent (lane & 7) of my half (agent-lane role)
     uint32_t prev0, prev1;
+    uint32_t scratch;        // a word nobody reads (record staging row, word kDummyWord of my half)
     uint64_t on_m, lead_m;   // lanes scanning a real agent; the first lane of each such group
 };
 static constexpr int kSelWord = 48, kDummyWord = 47;
@@ -1336,6 +1337,7 @@ __device__ __forceinline__ PairScanLane make_pair_scan_lane(const EnvLds& E, con
     q.selr = rec_h + (uint32_t)(kSelWord + 2 * (lane & 7)) * 4u;
     q.prev0 = lds_off(E.rec_s) + kDummyWord * 4u;
     q.prev1 = lds_off(E1.rec_s) + kDummyWord * 4u;
+    q.scratch = rec_h + kDummyWord * 4u;
     q.on_m = bal(on);
     q.lead_m = bal(on && sm.col == 0);
     return q;
@@ -1354,16 +1356,18 @@ __device__ __forceinline__ void scan_eval_pair1(PairScanLane& q, const ScanMap& 
     const uint64_t bo0 = bal(w0 <= g.ma0) & q.on_m, bo1 = bal(w1 <= g.ma1) & q.on_m;
     const uint64_t bq0 = bal(w0 <= g.mq0) & q.on_m, bq1 = bal(w1 <= g.mq1) & q.on_m;
     const bool own0 = lanes(bo0), own1 = lanes(bo1);
-    const uint32_t n0 = q.row0 + (g.ent0 & 0xffffu), n1 = q.row1 + (g.ent1 & 0xffffu);
-    if (own0) *lds_at<uint8_t>(n0) = 1;
-    if (own1) *lds_at<uint8_t>(n1) = 1;
-    q.prev0 = own0 ? n0 : q.prev0;
-    q.prev1 = own1 ? n1 : q.prev1;
+    // lanes without an affordable entry write the scratch word instead of being masked off: a select is
+    // cheaper than saving / restoring exec around every store
+    const uint32_t n0 = own0 ? q.row0 + (g.ent0 & 0xffffu) : q.scratch, n1 = own1 ? q.row1 + (g.ent1 & 0xffffu) : q.scratch;
+    *lds_at<uint8_t>(n0) = 1;
+    *lds_at<uint8_t>(n1) = 1;
+    q.prev0 = n0;      // the scratch byte is cleared like any other on the next step
+    q.prev1 = n1;
     const uint32_t gf0 = (uint32_t)(bo0 >> sm.gsh) & fmask, gf1 = (uint32_t)(bo1 >> sm.gsh) & fmask;
     const int rr0 = (int)__umulhi(g.xa0, (uint32_t)__popc(gf0)), rr1 = (int)__umulhi(g.xa1, (uint32_t)__popc(gf1));
     const uint64_t ch0 = bal(__popc(gf0 & sm.lowmask) == rr0) & bo0, ch1 = bal(__popc(gf1 & sm.lowmask) == rr1) & bo1;
-    if (lanes(ch0)) *lds_at<int>(q.selw0) = (int)g.ent0;
-    if (lanes(ch1)) *lds_at<int>(q.selw1) = (int)g.ent1;
+    *lds_at<int>(lanes(ch0) ? q.selw0 : q.scratch) = (int)g.ent0;
+    *lds_at<int>(lanes(ch1) ? q.selw1 : q.scratch) = (int)g.ent1;
     if (lanes(q.lead_m)) {
         lds_at<int>(q.selw0)[1] = __popc((uint32_t)(bq0 >> sm.gsh) & fmask);
         lds_at<int>(q.selw1)[1] = __popc((uint32_t)(bq1 >> sm.gsh) & fmask);
@@ -1545,6 +1549,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
     const int a0 = lane & 31;
     const int eh = (upper0 && live1) ? e + 1 : e;   // this lane's episode
     const bool store_ok = !upper0 || live1;
+    const bool all_store = live1;                   // wave-uniform: no lane of the wave is a shadow
     const uint16_t* __restrict__ ap = p.apsp + (size_t)g * N * N;
     const uint64_t gid = p.env_id_offset + (uint64_t)eh;
     const int n16 = (A * NS) >> 4;
@@ -1714,7 +1719,12 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
             uint4* md = reinterpret_cast<uint4*>(out.mask + (size_t)eh * (size_t)(A * NS)) + a;
             const uint4* mr = reinterpret_cast<const uint4*>(mrow_h) + a;
             const uint4 v0 = mr[0], v1 = mr[32], v2 = mr[64];
-            if (store_ok) {
+            if (all_store && n16 >= 64) {      // wave-uniform: both episodes live, the first two stores are full
+                md[0] = v0;
+                md[32] = v1;
+                if (a + 64 < n16) md[64] = v2;
+                for (int i = 96; a + i < n16; i += 32) md[i] = mr[i];
+            } else if (store_ok) {
                 if (a < n16) md[0] = v0;
                 if (a + 32 < n16) md[32] = v1;
                 if (a + 64 < n16) md[64] = v2;
@@ -1790,7 +1800,10 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         }
         if (REC) {
             int* rdst = out.record + (size_t)eh * RW;
-            if (store_ok) {
+            if (all_store && RW >= 32) {       // wave-uniform: the first store is full; RW == 32 has no second one
+                rdst[a] = recw0;
+                if (RW > 32 && a + 32 < RW) rdst[a + 32] = recw1;
+            } else if (store_ok) {
                 if (a < RW) rdst[a] = recw0;
                 if (a + 32 < RW) rdst[a + 32] = recw1;
             }

@@ -1744,26 +1744,12 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         SY_STAMP(4)
 
         // ---- D. rewards
-        int recw0 = 0, recw1 = 0;
         const double shaped = shaped_reward3(tb, a, P, POLM, t_v, qcnt, vc, dm, dj, kc);
         rew = lanes(ENDED) ? (lanes(CAP) ? (a == 0 ? -1.0 : 1.0) : (a == 0 ? 1.0 : 0.0)) : shaped;
         const int t_rec = t_v;
         t_v = lanes(NEED) ? 0 : t_v + 1;   // yard.py:355; a restarted episode begins at 0
         sc_v += 1u;
         SY_STAMP(5)
-        if (REC) {
-            if (a < A) {
-                rec_h[2 * a] = __double2loint(rew);
-                rec_h[2 * a + 1] = __double2hiint(rew);
-                rec_h[2 * A + a] = pos0_v;
-                rec_h[3 * A + a] = mon0_v;
-                rec_h[4 * A + a] = act_v;
-            }
-            if (a < 4) rec_h[5 * A + a] = a == 0 ? t_rec : (a == 1 ? term_v : (a == 2 ? trunc_v : win_v));
-            wave_lds_fence();
-            recw0 = rec_h[a];            // the row leaves LDS now and HBM-bound at the end of the step,
-            recw1 = rec_h[a + 32];       // so its LDS round trip overlaps the hand-off phase
-        }
 
         SY_STAMP(6)
         // ---- E. bookkeeping of a restart / reveal, and the hand-off to the belief wave
@@ -1799,13 +1785,16 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
             if (a == 0) lds_poke(sync_h, s + 1);
         }
         if (REC) {
+            // the packed row straight from the agent lanes: five narrow stores into one 128-byte line
             int* rdst = out.record + (size_t)eh * RW;
-            if (all_store && RW >= 32) {       // wave-uniform: the first store is full; RW == 32 has no second one
-                rdst[a] = recw0;
-                if (RW > 32 && a + 32 < RW) rdst[a + 32] = recw1;
-            } else if (store_ok) {
-                if (a < RW) rdst[a] = recw0;
-                if (a + 32 < RW) rdst[a + 32] = recw1;
+            if (store_ok) {
+                if (a < A) {
+                    *reinterpret_cast<double*>(rdst + 2 * a) = rew;
+                    rdst[2 * A + a] = pos0_v;
+                    rdst[3 * A + a] = mon0_v;
+                    rdst[4 * A + a] = act_v;
+                }
+                if (a < RW - 5 * A) rdst[5 * A + a] = a == 0 ? t_rec : (a == 1 ? term_v : (a == 2 ? trunc_v : (a == 3 ? win_v : 0)));
             }
             out.record += (size_t)B * RW;
             if (out.mask) out.mask += BA * NS;

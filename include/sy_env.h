@@ -67,7 +67,7 @@ typedef struct sy_env_config {
     int32_t police_evidence;   /* 1: belief is zeroed on police-occupied nodes                */
     int32_t belief_init_onehot;/* 1: belief starts as a delta on MrX's start (else uniform)   */
     int32_t auto_reset;        /* 1: a finished episode restarts inside step/rollout          */
-    int32_t waves_per_block;   /* envs per launch block (1..16, odd <= 9); 0 = engine default  */
+    int32_t waves_per_block;   /* envs per launch block (1..16, odd <= 7); 0 = engine default  */
     uint64_t env_id_offset;    /* global index of env 0 (rank * B): distinct RNG sub-streams  */
 } sy_env_config;
 

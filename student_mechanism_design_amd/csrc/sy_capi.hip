@@ -52,8 +52,8 @@ int sy_env_create(const sy_env_config* c, sy_env** out) {
         return fail(SY_ERR_INVALID, "agent_money must be in [0, 65534]%s");
     if (c->max_timestep < 0) return fail(SY_ERR_INVALID, "max_timestep must be >= 0%s");
     if (c->reveal_interval < 0) return fail(SY_ERR_INVALID, "reveal_interval must be >= 0%s");
-    if (c->waves_per_block < 0 || c->waves_per_block > 16 || (c->waves_per_block > 9 && (c->waves_per_block & 1)))
-        return fail(SY_ERR_INVALID, "waves_per_block must be in [0, 16], odd values at most 9%s");
+    if (c->waves_per_block < 0 || c->waves_per_block > 16 || (c->waves_per_block > 7 && (c->waves_per_block & 1)))
+        return fail(SY_ERR_INVALID, "waves_per_block must be in [0, 16], odd values at most 7%s");
     sy_env* e = new (std::nothrow) sy_env();
     if (!e) return fail(SY_ERR_INVALID, "out of host memory%s");
     std::memset(e, 0, sizeof(*e));
@@ -82,9 +82,10 @@ int sy_env_create(const sy_env_config* c, sy_env** out) {
     // so a 1024-thread block holds 16 episodes.  One such block fills a CU at 4 waves per SIMD: all waves of
     // the CU then have the same age and advance at the same rate, whereas two co-resident 8-episode blocks
     // finish 25 % apart (the instruction arbiter favours the older block) and leave the CU half empty
-    // for the tail of the launch.  Odd block sizes use the unpaired kernel (1.5 waves per episode: at most 9).
+    // for the tail of the launch.  Odd block sizes use the unpaired kernel (1.5 waves per episode, 768-thread
+    // blocks: at most 7).
     int wpb = c->waves_per_block ? c->waves_per_block : 16;
-    while (wpb > 1 && ell_bytes + (size_t)wpb * p.wave_lds_bytes > kMaxLds) wpb -= (wpb > 10) ? 2 : 1;
+    while (wpb > 1 && ell_bytes + (size_t)wpb * p.wave_lds_bytes > kMaxLds) wpb -= (wpb > 8) ? 2 : 1;
     if (ell_bytes + (size_t)wpb * p.wave_lds_bytes > kMaxLds) {
         delete e;
         return fail(SY_ERR_INVALID, "board does not fit in LDS%s");

@@ -109,7 +109,7 @@ def test_capi_argument_validation_without_gpu():
         sy._lib.EnvConfig(4, 2000, 2, 10, 250, 1, 2000, 0, 0, 0, 1, 0, 0),  # too many nodes
         sy._lib.EnvConfig(4, 10, 2, 10, 250, 0, 16, 0, 0, 0, 1, 0, 0),     # no graphs
         sy._lib.EnvConfig(4, 10, 2, 10, 250, 1, 16, 0, 0, 0, 1, 17, 0),    # waves per block
-        sy._lib.EnvConfig(4, 10, 2, 10, 250, 1, 16, 0, 0, 0, 1, 11, 0),    # odd block sizes use 1.5 waves/episode: <= 9
+        sy._lib.EnvConfig(4, 10, 2, 10, 250, 1, 16, 0, 0, 0, 1, 9, 0),     # odd block sizes use 1.5 waves/episode: <= 7
     ]
     for cfg in bad:
         assert lib.sy_env_create(C.byref(cfg), C.byref(h)) == -1
@@ -121,7 +121,7 @@ def test_capi_argument_validation_without_gpu():
     assert wpb.value * blocks.value >= 4096 and 0 < lds.value <= 160 * 1024
     assert wpb.value == 16 and blocks.value == 256        # BASELINE configs[1]: one 16-episode block per CU
     # explicit block sizes are honoured; a board too big for 16 episodes per block gets fewer (LDS is the limit)
-    for want, cfgv in ((12, (4096, 200, 4, 20, 250, 1, 208, 5, 0, 0, 1, 12, 0)), (9, (64, 70, 4, 9, 250, 1, 80, 2, 0, 0, 1, 9, 0))):
+    for want, cfgv in ((12, (4096, 200, 4, 20, 250, 1, 208, 5, 0, 0, 1, 12, 0)), (7, (64, 70, 4, 9, 250, 1, 80, 2, 0, 0, 1, 7, 0))):
         h2 = C.c_void_p()
         assert lib.sy_env_create(C.byref(sy._lib.EnvConfig(*cfgv)), C.byref(h2)) == 0
         assert lib.sy_env_launch_info(h2, C.byref(wpb), C.byref(blocks), C.byref(lds)) == 0 and wpb.value == want
@@ -129,7 +129,7 @@ def test_capi_argument_validation_without_gpu():
     h3 = C.c_void_p()
     assert lib.sy_env_create(C.byref(sy._lib.EnvConfig(64, 520, 2, 6, 250, 1, 528, 6, 0, 0, 1, 0, 0)), C.byref(h3)) == 0
     assert lib.sy_env_launch_info(h3, C.byref(wpb), C.byref(blocks), C.byref(lds)) == 0
-    assert 1 <= wpb.value < 16 and lds.value <= 160 * 1024 and (wpb.value <= 9 or wpb.value % 2 == 0)
+    assert 1 <= wpb.value < 16 and lds.value <= 160 * 1024 and (wpb.value <= 7 or wpb.value % 2 == 0)
     assert lib.sy_env_destroy(h3) == 0
     assert lib.sy_env_step(h, None, None) == -2       # call order error, not a crash
     assert lib.sy_env_rollout(h, 4, None, None) == -2

@@ -159,6 +159,8 @@ def test_step_matches_oracle(sy, ol, cfg):
     # odd block sizes / partial blocks: 7 envs per block, 3 belief waves + a half-used one
     dict(B=45, N=70, E=120, P=4, money=9, G=1, seed=17, reveal_interval=2, police_evidence=True, waves_per_block=7, T=40),
     dict(B=9, N=520, E=1000, P=2, money=6, G=1, seed=18, reveal_interval=6, waves_per_block=2, T=30),
+    # a board too big for 16 episodes per block: the engine picks the block size that fits the LDS
+    dict(B=37, N=520, E=1000, P=3, money=8, G=1, seed=19, reveal_interval=4, T=30),
 ])
 def test_fused_rollout_matches_oracle(sy, ol, cfg):
     cfg = dict(cfg)

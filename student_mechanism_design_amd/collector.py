@@ -117,23 +117,28 @@ class RolloutCollector:
     """Collect T steps of B envs into device tensors.
 
     policy(obs: dict) -> (actions int[B, A], log_prob [B, A] or None, value [B] / [B, A] or None).
+
+    `use_graph=True` (policy-driven collection on a GPU): the T-step loop — policy forward, `sy_env_step`,
+    record copies, a few dozen small kernels per step — is captured once into a HIP graph and replayed, so
+    a batched step costs one graph node chain instead of ~50 launches.  The first `collect()` runs eagerly
+    (it doubles as the warm-up capture needs), the second captures and replays, later ones replay.  The
+    policy must be capture-safe: fixed shapes, no host synchronisation, the default CUDA generator (or none).
     """
 
     def __init__(self, env, policy: Optional[Callable] = None, frames_per_batch: int = 64,
-                 record_mask: bool = True, record_belief: bool = True):
+                 record_mask: bool = True, record_belief: bool = True, use_graph: bool = False):
         self.env, self.policy, self.T = env, policy, int(frames_per_batch)
         self.record_mask, self.record_belief = record_mask, record_belief
         self._buf = env.alloc_rollout(self.T, record_mask, record_belief)
         B, A, dev = env.B, env.A, env.device
         self._logp = torch.zeros((self.T, B, A), dtype=torch.float32, device=dev)
         self._value = None
+        self.use_graph = bool(use_graph) and policy is not None
+        self._graph = None
+        self._calls = 0
 
-    @torch.no_grad()
-    def collect(self) -> Dict[str, torch.Tensor]:
+    def _policy_loop(self):
         env, T, buf = self.env, self.T, self._buf
-        if self.policy is None:
-            env.rollout(T, out=buf, record=True)
-            return {k: v for k, v in buf.items() if v is not None}
         for s in range(T):
             obs = env.observation()
             buf["pos"][s].copy_(env.pos)
@@ -157,6 +162,24 @@ class RolloutCollector:
             buf["terminated"][s].copy_(env._terminated)
             buf["truncated"][s].copy_(env._truncated)
             buf["winner"][s].copy_(env.winner)
+
+    @torch.no_grad()
+    def collect(self) -> Dict[str, torch.Tensor]:
+        env, T, buf = self.env, self.T, self._buf
+        if self.policy is None:
+            env.rollout(T, out=buf, record=True)
+            return {k: v for k, v in buf.items() if v is not None}
+        self._calls += 1
+        if not self.use_graph or self._calls == 1:
+            self._policy_loop()
+        else:
+            if self._graph is None:
+                torch.cuda.synchronize(env.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.device(env.device), torch.cuda.graph(g):
+                    self._policy_loop()            # recorded, not executed
+                self._graph = g
+            self._graph.replay()
         out = {k: v for k, v in buf.items() if v is not None}
         out["log_prob"] = self._logp
         if self._value is not None:

@@ -216,3 +216,44 @@ def test_step_and_rollout_are_hip_graph_capturable(sy):
     assert torch.equal(rec["record"], rec_g["record"]) and torch.equal(rec["belief"], rec_g["belief"])
     eager.close()
     graphed.close()
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def test_graph_captured_collector_is_a_faithful_trajectory(sy):
+    """use_graph=True: the T-step policy loop replayed as one HIP graph.  Every collected batch must be a
+    real trajectory of the engine: replaying its recorded actions through step() on a twin env reproduces
+    positions, masks, rewards and flags bit-exactly, across the eager, capture and replay calls."""
+    from student_mechanism_design_amd import collector as col, policies as pol
+    N, P, B, T = 60, 3, 96, 12
+    boards = sy.sample_board_pool(2, N, 100, seed=4)
+    w = np.linspace(0.1, 0.9, 11)
+    env = sy.BatchedScotlandYardEnv(B, boards, P, 12, w, seed=9, reveal_interval=4)
+    twin = sy.BatchedScotlandYardEnv(B, boards, P, 12, w, seed=9, reveal_interval=4)
+    net = pol.MappoPolicy(N, P, hidden_size=32).to(env.device)
+    c = col.RolloutCollector(env, net.act, frames_per_batch=T, use_graph=True)
+    for call in range(4):                       # eager, capture + replay, replay, replay
+        rec = c.collect()
+        torch.cuda.synchronize()
+        assert (call >= 1) == (c._graph is not None)
+        act = rec["action"].long()
+        legal = torch.gather(rec["mask"][..., :N].bool(), -1, act.clamp_min(0).unsqueeze(-1)).squeeze(-1)
+        assert bool((legal | (act < 0)).all())
+        for s in range(T):
+            np.testing.assert_array_equal(_np(twin.pos), _np(rec["pos"][s]), err_msg=f"call {call} step {s}")
+            np.testing.assert_array_equal(_np(twin._mask), _np(rec["mask"][s]))
+            twin.step(rec["action"][s].contiguous())
+            np.testing.assert_array_equal(_np(twin.reward), _np(rec["reward"][s]))
+            np.testing.assert_array_equal(_np(twin._terminated), _np(rec["terminated"][s]))
+        np.testing.assert_array_equal(_np(twin.pos), _np(env.pos))
+    # the policy's weights are live inside the graph: an in-place update changes what the replay samples
+    with torch.no_grad():
+        for prm in net.parameters():
+            prm.mul_(0.0)
+    rec = c.collect()
+    torch.cuda.synchronize()
+    assert torch.isfinite(rec["log_prob"]).all()
+    env.close()
+    twin.close()

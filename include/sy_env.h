@@ -149,6 +149,20 @@ int sy_belief_update(const uint32_t *ell, const float *inv_deg, int32_t num_node
                      float *belief, const int32_t *hint, int32_t hint_width, const int32_t *reveal,
                      int32_t num_queries, void *stream);
 
+/* replaces the masked sampling of MappoAgent.select_action (agent/mappo_agent.py:112-142), batched over
+ * num_rows = B * A (env, agent) rows, all device: probs float [rows][probs_row_stride] (the actor's softmax),
+ * mask uint8 [rows][mask_row_stride] (the engine's action masks: stride NS).  p = probs * mask; sum <= 1e-8 ->
+ * uniform over the mask (over all nodes if the mask is empty), else p / (sum + 1e-8); Categorical renormalises.
+ * Outputs: action int32 [rows] (-1 for an empty mask when default_on_empty != 0 = yard.py's DEFAULT_ACTION),
+ * log_prob float [rows] = log of the renormalised probability of the action, norm_probs float [rows][num_nodes]
+ * (NULL = not wanted).  Draws come from the engine's Philox stream (seed; row, offset + *offset_dev): pass a fresh
+ * offset per call, or keep a device-resident counter in offset_dev (NULL = none) so that a captured HIP graph
+ * draws fresh numbers on every replay. */
+int sy_masked_categorical_sample(const float *probs, int64_t probs_row_stride, const uint8_t *mask, int64_t mask_row_stride,
+                                 int32_t num_rows, int32_t num_nodes, uint64_t seed, uint64_t offset,
+                                 const uint64_t *offset_dev, int32_t default_on_empty, int32_t *action, float *log_prob,
+                                 float *norm_probs, void *stream);
+
 /* replaces Pathfinder.get_distance (pathfinding.py:34-137) for a whole pool: all-pairs weighted
  * shortest paths from the ELL table, apsp uint16 [G][N][N] (0xFFFF = unreachable); all device */
 int sy_build_apsp(const uint32_t *ell, int32_t num_nodes, int32_t num_graphs, uint16_t *apsp, void *stream);

@@ -37,7 +37,8 @@ class RolloutBuffers(C.Structure):
 
 EXPORTS = ["sy_abi_version", "sy_record_words", "sy_last_error", "sy_env_create", "sy_env_destroy", "sy_env_launch_info",
            "sy_env_set_graph_pool", "sy_env_set_rewards", "sy_env_bind_state", "sy_env_reset", "sy_env_reset_to",
-           "sy_env_step", "sy_env_rollout", "sy_action_mask_dense", "sy_belief_update", "sy_build_apsp", "sy_sample_boards"]
+           "sy_env_step", "sy_env_rollout", "sy_action_mask_dense", "sy_belief_update", "sy_build_apsp", "sy_sample_boards",
+           "sy_masked_categorical_sample"]
 
 _lib = None
 
@@ -70,6 +71,7 @@ def load():
     lib.sy_belief_update.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, i32, vp]
     lib.sy_build_apsp.argtypes = [vp, i32, i32, vp, vp]
     lib.sy_sample_boards.argtypes = [i32, i32, i32, i32, u64, i32, vp, vp, vp, vp, vp, i32, vp]
+    lib.sy_masked_categorical_sample.argtypes = [vp, C.c_int64, vp, C.c_int64, i32, i32, u64, u64, vp, i32, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("sy_last_error",):

@@ -37,6 +37,53 @@ def masked_categorical_sample(probs: torch.Tensor, mask: torch.Tensor, generator
     return a.reshape(p.shape[:-1]), logp.reshape(p.shape[:-1]), p
 
 
+class DeviceMaskedSampler:
+    """`masked_categorical_sample` as ONE HIP kernel (`sy_masked_categorical_sample`, include/sy_env.h): the
+    ~25 elementwise / reduction launches of the torch version — the bulk of a policy-in-the-loop step —
+    become one wave per (env, agent) row.  Same normalisation rules (mappo_agent.py:112-142); draws come
+    from the engine's Philox stream with a device-resident call counter, so a captured HIP graph samples
+    fresh numbers on every replay.  Fails loudly without the engine library / a GPU."""
+
+    def __init__(self, device, seed: int = 0):
+        from . import _lib
+        self._lib_mod = _lib
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.EngineError("DeviceMaskedSampler needs a GPU tensor device; there is no CPU fallback")
+        self.seed = int(seed) & (2**64 - 1)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)   # advanced after every call
+
+    def __call__(self, probs: torch.Tensor, mask: torch.Tensor, default_on_empty: bool = True, want_probs: bool = False):
+        """probs float32 [..., N]; mask uint8 / bool [..., >= N] (row stride may exceed N: the engine's NS).
+        Returns (action int32 [...], log_prob float32 [...], normalised probs [..., N] or None)."""
+        import ctypes as C
+        N = probs.shape[-1]
+        lead = tuple(probs.shape[:-1])
+        pr = probs.to(torch.float32).reshape(-1, N)
+        if pr.stride(-1) != 1:
+            pr = pr.contiguous()
+        mk = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+        mk = mk.reshape(-1, mk.shape[-1])
+        if mk.stride(-1) != 1:
+            mk = mk.contiguous()
+        if mk.shape[0] != pr.shape[0] or mk.shape[-1] < N:
+            raise ValueError("mask must have the rows of probs and at least N columns")
+        rows = pr.shape[0]
+        act = torch.empty(rows, dtype=torch.int32, device=self.device)
+        logp = torch.empty(rows, dtype=torch.float32, device=self.device)
+        norm = torch.empty((rows, N), dtype=torch.float32, device=self.device) if want_probs else None
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):
+            self._lib_mod.check(self.lib.sy_masked_categorical_sample(
+                C.c_void_p(pr.data_ptr()), C.c_int64(pr.stride(0)), C.c_void_p(mk.data_ptr()), C.c_int64(mk.stride(0)),
+                rows, N, C.c_uint64(self.seed), C.c_uint64(0), C.c_void_p(self.counter.data_ptr()),
+                1 if default_on_empty else 0, C.c_void_p(act.data_ptr()), C.c_void_p(logp.data_ptr()),
+                C.c_void_p(norm.data_ptr()) if norm is not None else None, stream), "sy_masked_categorical_sample")
+        self.counter.add_(1)
+        return act.reshape(lead), logp.reshape(lead), (norm.reshape(lead + (N,)) if norm is not None else None)
+
+
 def discounted_returns(rewards: torch.Tensor, dones: torch.Tensor, gamma: float) -> torch.Tensor:
     """R_t = r_t + gamma * R_{t+1} * (1 - done_t) along dim 0 (mappo_agent.py:248-254)."""
     T = rewards.shape[0]

@@ -232,6 +232,21 @@ int sy_belief_update(const uint32_t* ell, const float* inv_deg, int32_t num_node
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_belief_update launch");
 }
 
+int sy_masked_categorical_sample(const float* probs, int64_t probs_row_stride, const uint8_t* mask, int64_t mask_row_stride,
+                                 int32_t num_rows, int32_t num_nodes, uint64_t seed, uint64_t offset,
+                                 const uint64_t* offset_dev, int32_t default_on_empty, int32_t* action, float* log_prob,
+                                 float* norm_probs, void* stream) {
+    if (!probs || !mask || !action || !log_prob) return fail(SY_ERR_INVALID, "sy_masked_categorical_sample: null argument%s");
+    if (num_nodes < 1 || num_nodes > SY_MAX_NODES || probs_row_stride < num_nodes || mask_row_stride < num_nodes)
+        return fail(SY_ERR_INVALID, "sy_masked_categorical_sample: bad num_nodes / strides%s");
+    if (num_rows < 0) return fail(SY_ERR_INVALID, "sy_masked_categorical_sample: bad num_rows%s");
+    if (num_rows == 0) return SY_OK;
+    hipError_t e = sy::launch_masked_sample(probs, probs_row_stride, mask, mask_row_stride, num_rows, num_nodes, seed, offset,
+                                            offset_dev, default_on_empty ? 1 : 0, action, log_prob, norm_probs,
+                                            (hipStream_t)stream);
+    return e == hipSuccess ? SY_OK : hip_fail(e, "sy_masked_categorical_sample launch");
+}
+
 int sy_build_apsp(const uint32_t* ell, int32_t num_nodes, int32_t num_graphs, uint16_t* apsp, void* stream) {
     if (!ell || !apsp) return fail(SY_ERR_INVALID, "sy_build_apsp: null argument%s");
     if (num_nodes < 1 || num_nodes > SY_MAX_NODES || num_graphs < 1) return fail(SY_ERR_INVALID, "sy_build_apsp: bad sizes%s");

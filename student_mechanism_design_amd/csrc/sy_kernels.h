@@ -47,4 +47,8 @@ hipError_t launch_sample_boards(int N, int NS, int E_target, int max_deg_extra, 
                                 float* inv_deg, int32_t* edge_links, int32_t* edge_w, int32_t* num_edges, int E_cap,
                                 hipStream_t stream);
 
+hipError_t launch_masked_sample(const float* probs, long long probs_stride, const uint8_t* mask, long long mask_stride,
+                                int rows, int N, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                int default_on_empty, int32_t* action, float* log_prob, float* norm_out, hipStream_t stream);
+
 }  // namespace sy

@@ -2170,6 +2170,105 @@ __global__ __launch_bounds__(64) void sample_boards_kernel(int N, int NS, int E_
 }
 
 // ---------------------------------------------------------------------------------------------
+// masked_sample_kernel: MappoAgent.select_action's masked sampling (agent/mappo_agent.py:112-142),
+// one wave per (env, agent) row.  p = probs * mask; if its sum is <= 1e-8 the row falls back to
+// uniform over the mask (or over all nodes when the mask is empty), else p / (sum + 1e-8);
+// Categorical(probs = p) renormalises (norm = p / sum p), samples, and reports log norm[a].
+// Engine-defined draw: u = 24 bits of word 0 of Philox(seed; row, offset) in [0, 1); the action is
+// the first index whose inclusive prefix sum of norm (float32, node order) exceeds u.  Elements are
+// read coalesced (lane + 64 r) and the prefix is built per 64-node slab with DPP scans.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {   // inclusive prefix sum over the 64 lanes
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));   // row_shr:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true));   // row_shr:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, true));   // row_shr:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, true));   // row_shr:8
+    // rows of 16 are scanned; add the totals of the rows below
+    const int iv = __float_as_int(v);
+    const float r0 = __int_as_float(rdlane(iv, 15)), r1 = __int_as_float(rdlane(iv, 31)), r2 = __int_as_float(rdlane(iv, 47));
+    const int row = lane >> 4;
+    return v + (row == 0 ? 0.0f : (row == 1 ? r0 : (row == 2 ? r0 + r1 : (r0 + r1) + r2)));
+}
+
+template <int NR>
+__global__ __launch_bounds__(256) void masked_sample_kernel(const float* __restrict__ probs, long long probs_stride,
+                                                            const uint8_t* __restrict__ mask, long long mask_stride, int rows,
+                                                            int N, uint32_t seed_lo, uint32_t seed_hi, uint64_t offset_imm,
+                                                            const uint64_t* __restrict__ offset_dev,
+                                                            int default_on_empty, int32_t* __restrict__ action,
+                                                            float* __restrict__ log_prob, float* __restrict__ norm_out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* pr = probs + (size_t)row * probs_stride;
+    const uint8_t* mr = mask + (size_t)row * mask_stride;
+    float pv[NR], mv[NR];
+    float s_loc = 0.0f, m_loc = 0.0f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = lane + 64 * r;
+        mv[r] = (j < N && mr[j]) ? 1.0f : 0.0f;
+        pv[r] = j < N ? pr[j] * mv[r] : 0.0f;
+        s_loc += pv[r];
+        m_loc += mv[r];
+    }
+    const float s = wave_sum(s_loc), msum = wave_sum(m_loc);
+    // mappo_agent.py:120-129
+    const bool degenerate = s <= 1e-8f;
+    const bool empty = !(msum > 1e-8f);
+    const float inv_s = 1.0f / (s + 1e-8f), inv_m = empty ? 0.0f : 1.0f / msum, uni = 1.0f / (float)N;
+    float t_loc = 0.0f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = lane + 64 * r;
+        pv[r] = degenerate ? (empty ? (j < N ? uni : 0.0f) : mv[r] * inv_m) : pv[r] * inv_s;
+        t_loc += pv[r];
+    }
+    const float total = wave_sum(t_loc);
+    const float inv_t = 1.0f / total;
+    // the draw; a device-resident offset lets a captured HIP graph advance the stream between replays
+    const uint64_t offset = offset_imm + (offset_dev ? *offset_dev : 0ull);
+    uint32_t o[4];
+    philox4((uint64_t)row, (uint32_t)offset, 3u, (uint32_t)(offset >> 32) & 0xffu, seed_lo, seed_hi, o);
+    const float u = (float)(o[0] >> 8) * (1.0f / 16777216.0f);
+    float base = 0.0f;
+    int found = 0x7fffffff;
+    float p_found = 0.0f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = lane + 64 * r;
+        const float nv = pv[r] * inv_t;                       // Categorical's renormalised probability
+        if (norm_out && j < N) norm_out[(size_t)row * N + j] = nv;
+        const float incl = base + wave_incl_scan(nv, lane);
+        if (nv > 0.0f && incl > u && j < found) { found = j; p_found = nv; }
+        base = __int_as_float(rdlane(__float_as_int(incl), 63));
+    }
+    // first hit in node order = smallest j over the lanes; rounding may leave u above the last prefix:
+    // then the last node with positive probability is taken
+    int last_pos = -1;
+    float p_last = 0.0f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int j = lane + 64 * r;
+        if (pv[r] > 0.0f && j > last_pos) { last_pos = j; p_last = pv[r] * inv_t; }
+    }
+    int best = found, bl = last_pos;
+#pragma unroll
+    for (int o2 = 32; o2 >= 1; o2 >>= 1) {
+        const int ob = __shfl_xor(best, o2, kWave), ol = __shfl_xor(bl, o2, kWave);
+        best = ob < best ? ob : best;
+        bl = ol > bl ? ol : bl;
+    }
+    const int a = best != 0x7fffffff ? best : bl;
+    const float pa_mine = (found == a) ? p_found : ((last_pos == a && best == 0x7fffffff) ? p_last : 0.0f);
+    const float pa = wave_sum(pa_mine);                          // exactly one lane holds it
+    if (lane == 0) {
+        action[row] = (empty && default_on_empty) ? -1 : a;
+        log_prob[row] = logf(pa);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launchers (called from the C ABI, sy_capi.hip)
 // ---------------------------------------------------------------------------------------------
 template <int NR>
@@ -2275,6 +2374,25 @@ hipError_t launch_sample_boards(int N, int NS, int E_target, int max_deg_extra, 
     const int max_rounds = 64 * N + 4096;
     hipLaunchKernelGGL(sample_boards_kernel, dim3(G), dim3(64), lds, stream, N, NS, E_target, max_deg_extra, (uint32_t)seed,
                        (uint32_t)(seed >> 32), G, max_rounds, ell, inv_deg, edge_links, edge_w, num_edges, E_cap);
+    return hipGetLastError();
+}
+
+hipError_t launch_masked_sample(const float* probs, long long probs_stride, const uint8_t* mask, long long mask_stride,
+                                int rows, int N, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
+                                int default_on_empty, int32_t* action, float* log_prob, float* norm_out, hipStream_t stream) {
+    const int wpb = 4, blocks = (rows + wpb - 1) / wpb;
+    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    const int nr = (N + 63) / 64;
+#define SY_LAUNCH_MS(NR_) hipLaunchKernelGGL((masked_sample_kernel<NR_>), dim3(blocks), dim3(wpb * 64), 0, stream, probs,    \
+                                             probs_stride, mask, mask_stride, rows, N, lo, hi, offset, offset_dev,            \
+                                             default_on_empty,                                                                \
+                                             action, log_prob, norm_out)
+    if (nr <= 1) SY_LAUNCH_MS(1);
+    else if (nr <= 2) SY_LAUNCH_MS(2);
+    else if (nr <= 4) SY_LAUNCH_MS(4);
+    else if (nr <= 8) SY_LAUNCH_MS(8);
+    else SY_LAUNCH_MS(16);
+#undef SY_LAUNCH_MS
     return hipGetLastError();
 }
 

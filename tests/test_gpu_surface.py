@@ -257,3 +257,69 @@ def test_graph_captured_collector_is_a_faithful_trajectory(sy):
     assert torch.isfinite(rec["log_prob"]).all()
     env.close()
     twin.close()
+
+
+def test_device_masked_sampler_matches_select_action_rules(sy):
+    """sy_masked_categorical_sample vs the batched restatement of MappoAgent.select_action
+    (collector.masked_categorical_sample, mappo_agent.py:112-142): identical renormalised probabilities
+    incl. the two fallbacks, legal actions, log-probabilities of the drawn actions, fresh draws per call,
+    and the right distribution."""
+    from student_mechanism_design_amd import collector as col
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device="cpu").manual_seed(11)
+    R, N, NS = 3000, 200, 208
+    probs = torch.softmax(torch.randn(R, N, generator=g) * 2.0, -1)
+    mask = torch.zeros(R, NS, dtype=torch.uint8)
+    mask[:, :N] = (torch.rand(R, N, generator=g) < 0.04).to(torch.uint8)
+    mask[5] = 0                                   # empty mask -> uniform over all nodes, action -1
+    probs[7] = 0.0
+    probs[7, 3] = 1.0
+    mask[7] = 0
+    mask[7, 10:14] = 1                            # all probability mass masked out -> uniform over the mask
+    mask[:, N:] = 1                               # padding columns beyond N must be ignored
+    probs_d, mask_d = probs.to(dev), mask.to(dev)
+    smp = col.DeviceMaskedSampler(dev, seed=123)
+    a, logp, norm = smp(probs_d, mask_d, default_on_empty=True, want_probs=True)
+    _, _, p_ref = col.masked_categorical_sample(probs, mask[:, :N].bool())
+    ref_norm = p_ref / p_ref.sum(-1, keepdim=True)
+    np.testing.assert_allclose(norm.cpu().numpy(), ref_norm.numpy(), rtol=2e-5, atol=1e-7)
+    a_c, logp_c = a.cpu().long(), logp.cpu()
+    assert int(a_c[5]) == -1 and 10 <= int(a_c[7]) < 14
+    ok = mask[:, :N].sum(-1) > 0                  # rows with at least one legal node (row 5 and the odd random one are not)
+    assert not bool(ok[5]) and bool((a_c[~ok] == -1).all()) and bool((a_c[ok] >= 0).all())
+    legal = torch.gather(mask[:, :N].bool(), -1, a_c.clamp_min(0).unsqueeze(-1)).squeeze(-1)
+    assert bool(legal[ok].all())
+    want_lp = torch.log(torch.gather(ref_norm, -1, a_c.clamp_min(0).unsqueeze(-1)).squeeze(-1))
+    np.testing.assert_allclose(logp_c[ok].numpy(), want_lp[ok].numpy(), rtol=1e-4, atol=1e-5)
+    # a new call draws new numbers; the same (seed, counter) reproduces
+    a2, _, _ = smp(probs_d, mask_d)
+    assert not torch.equal(a, a2)
+    smp2 = col.DeviceMaskedSampler(dev, seed=123)
+    a3, _, _ = smp2(probs_d, mask_d)
+    assert torch.equal(a, a3)
+    a4, _, _ = col.DeviceMaskedSampler(dev, seed=124)(probs_d, mask_d)
+    assert not torch.equal(a, a4)
+    # distribution: one row replicated (each row has its own stream)
+    K = 40000
+    row_p = torch.tensor([0.5, 0.0, 0.25, 0.125, 0.0, 0.125] + [0.0] * 64, dtype=torch.float32)
+    row_m = torch.ones(70, dtype=torch.uint8)
+    row_m[3] = 0                                   # renormalised over {0, 2, 5}: 4/7, 2/7, 1/7
+    ak, _, _ = col.DeviceMaskedSampler(dev, seed=5)(row_p.repeat(K, 1).to(dev), row_m.repeat(K, 1).to(dev))
+    freq = torch.bincount(ak.cpu().long(), minlength=70).double() / K
+    np.testing.assert_allclose(freq[[0, 2, 5]].numpy(), [4 / 7, 2 / 7, 1 / 7], atol=0.01)
+    assert bool(((ak == 0) | (ak == 2) | (ak == 5)).all())
+    # graph capture: the device-resident counter advances between replays
+    x = probs_d[:64].contiguous()
+    m = mask_d[:64].contiguous()
+    smp3 = col.DeviceMaskedSampler(dev, seed=9)
+    smp3(x, m)
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        ag, _, _ = smp3(x, m)
+    gr.replay()
+    torch.cuda.synchronize()
+    first = ag.clone()
+    gr.replay()
+    torch.cuda.synchronize()
+    assert not torch.equal(first, ag)

@@ -37,6 +37,20 @@ def test_mappo_policy_shapes_and_masking():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
 
 
+def test_mappo_fast_inference_path_is_the_same_function():
+    B, N, P = 48, 40, 4
+    obs = _fake_obs(B, N, P, seed=3)
+    net = pol.MappoPolicy(N, P, hidden_size=16)
+    torch.testing.assert_close(net.probs_fast(obs), net.probs(obs), rtol=1e-5, atol=1e-7)
+    torch.testing.assert_close(net.value_fast(obs), net.value(obs), rtol=1e-5, atol=1e-6)
+    a1, lp1, v1 = net.act(obs, generator=torch.Generator().manual_seed(5))
+    a2, lp2, v2 = net.act_fast(obs, generator=torch.Generator().manual_seed(5))
+    assert torch.equal(a1 < 0, a2 < 0)
+    legal = torch.gather(obs["action_mask"], -1, a2.clamp_min(0).long().unsqueeze(-1)).squeeze(-1)
+    assert bool((legal | (a2 < 0)).all())
+    torch.testing.assert_close(v1, v2, rtol=1e-5, atol=1e-6)
+
+
 def test_antisymmetric_conv_matches_its_formula():
     torch.manual_seed(0)
     boards = sy.sample_board_pool(2, 12, 18, seed=1)

@@ -20,8 +20,14 @@ boards = sy.sample_board_pool(8, N, 400, seed=0)
 env = sy.BatchedScotlandYardEnv(B, boards, P, 20, np.full(11, 0.5), seed=1234, reveal_interval=5)
 env.reset(seed=1)
 pol = MappoPolicy(N, P).to(env.device)
-for use_graph in (False, True):
-    col = RolloutCollector(env, pol.act, frames_per_batch=T, use_graph=use_graph)
+from student_mechanism_design_amd.collector import DeviceMaskedSampler  # noqa: E402
+smp = DeviceMaskedSampler(env.device, seed=7)
+for use_graph, fn, name in ((False, pol.act, "reference-shaped forward, torch sampling"),
+                            (True, pol.act, "reference-shaped forward, torch sampling"),
+                            (True, pol.act_fast, "lookup + batched-matmul forward, torch sampling"),
+                            (False, lambda obs: pol.act_device(obs, smp), "lookup + batched-matmul forward, HIP sampling kernel"),
+                            (True, lambda obs: pol.act_device(obs, smp), "lookup + batched-matmul forward, HIP sampling kernel")):
+    col = RolloutCollector(env, fn, frames_per_batch=T, use_graph=use_graph)
     col.collect()
     col.collect()          # (graph mode: capture + first replay)
     torch.cuda.synchronize()
@@ -31,7 +37,7 @@ for use_graph in (False, True):
         col.collect()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"collector + MAPPO policy, {'HIP graph replay' if use_graph else 'eager launches'}: "
+    print(f"collector + MAPPO policy ({name}), {'HIP graph replay' if use_graph else 'eager launches'}: "
           f"{reps * T * B * (P + 1) / dt / 1e6:.1f} M agent-steps/s ({dt / (reps * T) * 1e3:.3f} ms per batched step of {B} envs)")
 # env.step alone, same loop without the policy (actions replayed)
 rec = env.rollout(1)

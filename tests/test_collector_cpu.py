@@ -10,6 +10,26 @@ import torch.multiprocessing as mp
 from student_mechanism_design_amd import collector as col
 
 
+def _select_action_goldens():
+    import json
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "select_action_reference.json")) as f:
+        return json.load(f)["cases"]
+
+
+def test_masked_sampling_matches_the_reference_goldens():
+    """tests/golden/select_action_reference.json: outputs of the UNMODIFIED MappoAgent.select_action
+    (oracle/capture_select_action.py).  The batched restatement must produce the same normalised
+    probabilities, and the reference's log-prob of the action it drew."""
+    for c in _select_action_goldens():
+        probs, mask = torch.tensor(c["probs"]), torch.tensor(c["mask"], dtype=torch.float32)
+        _, _, p = col.masked_categorical_sample(probs.unsqueeze(0), mask.unsqueeze(0))
+        np.testing.assert_allclose(p[0].numpy(), np.array(c["current_probs"], dtype=np.float32), rtol=1e-6, atol=1e-9,
+                                   err_msg=c["kind"])
+        norm = p[0] / p[0].sum()
+        np.testing.assert_allclose(float(torch.log(norm[c["action"]])), c["log_prob"], rtol=1e-5, atol=1e-6)
+        assert c["kind"] == "empty_mask" or c["mask"][c["action"]] == 1
+
+
 def test_masked_sampling_follows_mappo_select_action():
     """agent/mappo_agent.py:87-142: illegal actions get zero probability; all-zero product -> uniform
     over the mask; empty mask -> uniform over everything; result renormalised."""

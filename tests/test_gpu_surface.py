@@ -323,3 +323,26 @@ def test_device_masked_sampler_matches_select_action_rules(sy):
     gr.replay()
     torch.cuda.synchronize()
     assert not torch.equal(first, ag)
+
+
+def test_device_masked_sampler_against_the_reference_goldens(sy):
+    """The HIP sampling kernel on the probability / mask vectors the unmodified reference was run on
+    (tests/golden/select_action_reference.json): same renormalised distribution, and the log-prob it reports
+    for its own draw is the reference distribution's."""
+    import json
+    import os
+    from student_mechanism_design_amd import collector as col
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "select_action_reference.json")) as f:
+        cases = json.load(f)["cases"]
+    dev = torch.device("cuda", 0)
+    smp = col.DeviceMaskedSampler(dev, seed=2024)
+    for c in cases:
+        probs = torch.tensor(c["probs"], dtype=torch.float32, device=dev).unsqueeze(0)
+        mask = torch.tensor(c["mask"], dtype=torch.uint8, device=dev).unsqueeze(0)
+        a, logp, norm = smp(probs, mask, default_on_empty=False, want_probs=True)
+        cur = np.array(c["current_probs"], dtype=np.float64)
+        ref_norm = cur / cur.sum()
+        np.testing.assert_allclose(norm[0].cpu().numpy(), ref_norm, rtol=2e-5, atol=1e-7, err_msg=c["kind"])
+        ai = int(a[0])
+        assert ref_norm[ai] > 0 and (c["kind"] == "empty_mask" or c["mask"][ai] == 1)
+        np.testing.assert_allclose(float(logp[0]), np.log(ref_norm[ai]), rtol=1e-4, atol=1e-5)

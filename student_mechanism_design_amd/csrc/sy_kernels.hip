@@ -242,7 +242,7 @@ __device__ __forceinline__ void scan_sample(const uint32_t* ell_s, uint8_t* mrow
         if (own) mrow[a * NS + (int)(ent & 0xffffu)] = 1;
         const uint32_t gfield = (uint32_t)(bo >> sm.gsh) & fmask;           // this lane's agent's affordable entries
         const int rr = (int)__umulhi(xa, (uint32_t)__popc(gfield));
-        const bool chosen = own && __popc(gfield & sm.lowmask) == rr;
+        const bool chosen = own && (int)__popc(gfield & sm.lowmask) == rr;
         const uint64_t bc = __ballot(chosen);
         const uint32_t cf = (uint32_t)(bc >> sm.ash) & fmask;               // agent lane's chosen column, one-hot
         const int from = sm.ash + (cf ? __ffs((int)cf) - 1 : 0);
@@ -310,7 +310,7 @@ __device__ __forceinline__ void scan_eval_pair(const uint32_t* ell_s, uint8_t* m
         if (own1) mrow1[a * NS + (int)(g.ent1 & 0xffffu)] = 1;
         const uint32_t gf0 = (uint32_t)(bo0 >> sm.gsh) & fmask, gf1 = (uint32_t)(bo1 >> sm.gsh) & fmask;
         const int rr0 = (int)__umulhi(g.xa0, (uint32_t)__popc(gf0)), rr1 = (int)__umulhi(g.xa1, (uint32_t)__popc(gf1));
-        const bool ch0 = own0 && __popc(gf0 & sm.lowmask) == rr0, ch1 = own1 && __popc(gf1 & sm.lowmask) == rr1;
+        const bool ch0 = own0 && (int)__popc(gf0 & sm.lowmask) == rr0, ch1 = own1 && (int)__popc(gf1 & sm.lowmask) == rr1;
         const uint64_t bc0 = __ballot(ch0), bc1 = __ballot(ch1);
         // agent lanes: lower half takes episode 0's ballots, upper half episode 1's
         const uint64_t bc = upper ? bc1 : bc0, bq = upper ? bq1 : bq0;
@@ -1365,7 +1365,7 @@ __device__ __forceinline__ void scan_eval_pair1(PairScanLane& q, const ScanMap& 
     q.prev1 = n1;
     const uint32_t gf0 = (uint32_t)(bo0 >> sm.gsh) & fmask, gf1 = (uint32_t)(bo1 >> sm.gsh) & fmask;
     const int rr0 = (int)__umulhi(g.xa0, (uint32_t)__popc(gf0)), rr1 = (int)__umulhi(g.xa1, (uint32_t)__popc(gf1));
-    const uint64_t ch0 = bal(__popc(gf0 & sm.lowmask) == rr0) & bo0, ch1 = bal(__popc(gf1 & sm.lowmask) == rr1) & bo1;
+    const uint64_t ch0 = bal((int)__popc(gf0 & sm.lowmask) == rr0) & bo0, ch1 = bal((int)__popc(gf1 & sm.lowmask) == rr1) & bo1;
     *lds_at<int>(lanes(ch0) ? q.selw0 : q.scratch) = (int)g.ent0;
     *lds_at<int>(lanes(ch1) ? q.selw1 : q.scratch) = (int)g.ent1;
     if (lanes(q.lead_m)) {

@@ -474,3 +474,75 @@ def test_device_board_sampler_statistics_and_use(sy, ol):
     for k in ("pos", "action", "mask", "reward", "terminated"):
         np.testing.assert_array_equal(_np(rec[k]), ref[k], err_msg=k)
     env.close()
+
+
+def _random_board(sy, rng, n, extra, wmax, wmin=0):
+    """Connected board: random spanning tree + `extra` random edges (duplicates dropped), weights in
+    [wmin, wmax] — including zero-weight edges, which the reference's weights never are but the ABI admits."""
+    order = rng.permutation(n)
+    links = set()
+    for i in range(1, n):
+        u, v = int(order[i]), int(order[rng.integers(0, i)])
+        links.add((min(u, v), max(u, v)))
+    deg = np.zeros(n, int)
+    for u, v in links:
+        deg[u] += 1
+        deg[v] += 1
+    tries = 0
+    while extra > 0 and tries < 50 * n:
+        tries += 1
+        u, v = int(rng.integers(0, n)), int(rng.integers(0, n))
+        e = (min(u, v), max(u, v))
+        if u == v or e in links or deg[u] >= 15 or deg[v] >= 15:
+            continue
+        links.add(e)
+        deg[u] += 1
+        deg[v] += 1
+        extra -= 1
+    links = sorted(links)
+    w = rng.integers(wmin, wmax + 1, size=len(links))
+    return sy.make_board(n, np.array(links, dtype=np.int32), w)
+
+
+@pytest.mark.parametrize("case", range(40))
+def test_randomised_configurations_match_the_oracle(sy, ol, case):
+    """Engine vs oracle over randomly drawn shapes and switches: node / police counts, tiny budgets, zero and
+    heavy edge weights, short episode caps (timeouts), reveal schedules, police evidence, one-hot priors,
+    board pools, odd batch sizes and block sizes — fused rollout, then caller-action steps from the live state."""
+    rng = np.random.default_rng(4242 + case)
+    N = int(rng.integers(8, 90))
+    P = int(rng.integers(1, 8))
+    if P + 1 > N - 2:
+        P = max(1, N - 3)
+    G = int(rng.integers(1, 4))
+    money = int(rng.choice([0, 1, 2, 3, 5, 9, 30]))
+    wmax = int(rng.choice([1, 2, 4, 7]))
+    wmin = int(rng.choice([0, 1]))
+    B = int(rng.integers(3, 70))
+    T = int(rng.integers(20, 70))
+    kw = dict(reveal_interval=int(rng.integers(0, 5)), police_evidence=bool(rng.integers(0, 2)),
+              belief_init_onehot=bool(rng.integers(0, 2)), max_timestep=int(rng.choice([3, 8, 20, 250])),
+              waves_per_block=int(rng.choice([0, 0, 2, 3, 4, 5, 6, 7, 8, 12, 16])))
+    boards = [_random_board(sy, rng, N, int(rng.integers(0, 2 * N)), wmax, wmin) for _ in range(G)]
+    weights = rng.uniform(0.0, 1.0, 11)
+    weights[rng.integers(0, 11)] = 0.0
+    env = sy.BatchedScotlandYardEnv(B, boards, P, money, weights, seed=case, **kw)
+    graphs = [ol.OracleGraph(N, b.edge_links, b.edges.astype(np.int32)) for b in boards]
+    orc = ol.OracleBatch(graphs, env.env_graph_host, B, P, money, max_t=kw["max_timestep"], node_stride=env.NS,
+                         weights=weights, tables=sy.reward_tables(), reveal_interval=kw["reveal_interval"],
+                         police_evidence=kw["police_evidence"], belief_init_onehot=kw["belief_init_onehot"])
+    orc.reset(seed=case)
+    _compare_state(env, orc, f"case {case} after reset")
+    rec = env.rollout(T)
+    ref = orc.rollout(T)
+    for k in ("pos", "t", "action", "terminated", "truncated", "winner", "mask", "reward"):
+        np.testing.assert_array_equal(_np(rec[k]), ref[k], err_msg=f"case {case} {k}")
+    np.testing.assert_array_equal(_np(rec["budget"]), ref["money"], err_msg="budget")
+    np.testing.assert_allclose(_np(rec["belief"]), ref["belief"], rtol=0, atol=BELIEF_TOL)
+    _compare_state(env, orc, f"case {case} after rollout")
+    for s in range(6):
+        act = _random_actions(rng, orc.pos, orc.mask[:, :, :N], N)
+        env.step(torch.as_tensor(act, device=env.device))
+        orc.step(act)
+        _compare_state(env, orc, f"case {case} step {s}")
+    env.close()

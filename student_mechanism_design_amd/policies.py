@@ -2,7 +2,9 @@
 in PyTorch, only the env is a HIP engine.
 
 * `MappoPolicy` — the networks of `src/agent/mappo_agent.py:6-44` (per-agent 2-layer MLP actors with a
-  softmax head, one central 2-layer MLP critic), evaluated for all B envs at once.  Observations follow
+  softmax head, one central 2-layer MLP critic), evaluated for all B envs at once.  **Parity pinned**:
+  tests/golden/mappo_networks_reference.npz holds weights / inputs / outputs of the unmodified reference
+  networks (oracle/capture_mappo_networks.py); tests/test_policies_cpu.py loads them into this class.  Observations follow
   the trainer (`mappo_trainer.py:173,197`): MrX sees one-hot(MrX_pos), every police sees the multi-hot
   of all police positions; the critic sees their concatenation.
 * `AntiSymmetricConvDense` / `GnnQPolicy` — pure-torch restatement of the model in

@@ -37,6 +37,33 @@ def test_mappo_policy_shapes_and_masking():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
 
 
+def test_mappo_policy_matches_the_reference_networks():
+    """tests/golden/mappo_networks_reference.npz: weights, inputs and outputs of the UNMODIFIED AgentPolicy /
+    CentralCritic (oracle/capture_mappo_networks.py).  MappoPolicy loaded with those weights must reproduce the
+    reference's action probabilities and values, through both the reference-shaped and the one-hot-free path."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mappo_networks_reference.npz"))
+    N, P, H = int(g["N"]), int(g["P"]), int(g["H"])
+    net = pol.MappoPolicy(N, P, hidden_size=H)
+    with torch.no_grad():
+        for k in range(P + 1):
+            net.actors[k][0].weight.copy_(torch.from_numpy(g[f"actor{k}.actor.0.weight"]))
+            net.actors[k][0].bias.copy_(torch.from_numpy(g[f"actor{k}.actor.0.bias"]))
+            net.actors[k][2].weight.copy_(torch.from_numpy(g[f"actor{k}.actor.2.weight"]))
+            net.actors[k][2].bias.copy_(torch.from_numpy(g[f"actor{k}.actor.2.bias"]))
+        net.critic[0].weight.copy_(torch.from_numpy(g["critic.critic.0.weight"]))
+        net.critic[0].bias.copy_(torch.from_numpy(g["critic.critic.0.bias"]))
+        net.critic[2].weight.copy_(torch.from_numpy(g["critic.critic.2.weight"]))
+        net.critic[2].bias.copy_(torch.from_numpy(g["critic.critic.2.bias"]))
+    pos = torch.from_numpy(g["pos"])
+    obs = {"MrX_pos": pos[:, 0], "Polices_pos": pos[:, 1:]}
+    with torch.no_grad():
+        np.testing.assert_allclose(net.probs(obs).numpy(), g["probs"], rtol=1e-6, atol=1e-8)
+        np.testing.assert_allclose(net.value(obs).numpy(), g["value"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(net.probs_fast(obs).numpy(), g["probs"], rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(net.value_fast(obs).numpy(), g["value"], rtol=1e-5, atol=1e-6)
+
+
 def test_mappo_fast_inference_path_is_the_same_function():
     B, N, P = 48, 40, 4
     obs = _fake_obs(B, N, P, seed=3)

@@ -43,3 +43,34 @@ def test_rollout_metrics_aggregate_like_metrics_tracker():
     assert abs(float(m["mean_episode_length"]) - (3 + 6 + 5) / 3) < 1e-6
     assert float(m["mean_time_to_catch"]) == 3.0 and float(m["mean_survival_time"]) == 5.5
     assert abs(float(m["mean_belief_ce"]) - (-np.log(0.1))) < 1e-6 and float(m["belief_ce_std"]) < 1e-6
+
+
+def test_metrics_match_the_reference_goldens():
+    """tests/golden/metrics_reference.json: outputs of the UNMODIFIED eval/metrics.py (oracle/capture_metrics.py):
+    belief_cross_entropy on 24 beliefs, and MetricsTracker aggregates over 37 episodes, which are laid out here
+    as a rollout record (one env per episode, finishing at step length - 1 with the recorded winner)."""
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metrics_reference.json")) as f:
+        g = json.load(f)
+    for c in g["ce_cases"]:
+        got = M.belief_cross_entropy(torch.tensor(c["belief"], dtype=torch.float64), torch.tensor(c["true_index"]))
+        assert abs(float(got) - c["ce"]) < 1e-10
+    eps = g["episodes"]
+    T, B, A = max(e["length"] for e in eps), len(eps), 3
+    rec = {
+        "terminated": torch.zeros(T, B, dtype=torch.int32), "truncated": torch.zeros(T, B, dtype=torch.int32),
+        "winner": torch.zeros(T, B, dtype=torch.int32), "t": torch.arange(T).unsqueeze(1).expand(T, B).clone().int(),
+        "budget": torch.full((T, B, A), 5, dtype=torch.int32), "pos": torch.zeros(T, B, A, dtype=torch.int32),
+    }
+    for b, e in enumerate(eps):
+        s = e["length"] - 1
+        rec["terminated"][s, b] = 1
+        rec["winner"][s, b] = 1 if e["winner"] == "Police" else 2
+        rec["t"][s + 1:, b] = 0           # (rows after the end belong to the next episode; they finish nothing)
+    m = M.rollout_metrics(rec, 10)
+    a = g["aggregated"]
+    assert int(m["num_episodes"]) == int(a["num_episodes"]) and int(m["mrx_wins"]) == int(a["mrx_wins"])
+    assert int(m["police_wins"]) == int(a["police_wins"])
+    for k in ("win_rate", "mean_episode_length", "mean_time_to_catch", "mean_survival_time"):
+        assert abs(float(m[k]) - a[k]) < 1e-4 * max(1.0, abs(a[k])), k

@@ -132,6 +132,12 @@ int sy_env_reset_to(sy_env *env, const int32_t *starts, void *stream);
 /* replaces CustomEnvironment.step (yard.py:144-269): actions device int32[B][A], node id or -1 */
 int sy_env_step(sy_env *env, const int32_t *actions, void *stream);
 
+/* sy_env_step that also fills one row of a rollout record (the trainer's per-step stores,
+ * mappo_trainer.py:236-262): `row` holds the addresses of row s of the three buffers of
+ * sy_rollout_buffers — the observation before the step (mask [B][A][NS], belief [B][NS]) and the packed
+ * {reward, pos, budget, action, t, flags} row [B][RW]; null members are skipped */
+int sy_env_step_record(sy_env *env, const int32_t *actions, const sy_rollout_buffers *row, void *stream);
+
 /* replaces the rollout loop (mappo_trainer.py:161-287) with the uniform-random policy
  * (random_agent.py): T fused steps in ONE launch, records into `out` (may be NULL) */
 int sy_env_rollout(sy_env *env, int32_t T, const sy_rollout_buffers *out, void *stream);

@@ -37,7 +37,7 @@ class RolloutBuffers(C.Structure):
 
 EXPORTS = ["sy_abi_version", "sy_record_words", "sy_last_error", "sy_env_create", "sy_env_destroy", "sy_env_launch_info",
            "sy_env_set_graph_pool", "sy_env_set_rewards", "sy_env_bind_state", "sy_env_reset", "sy_env_reset_to",
-           "sy_env_step", "sy_env_rollout", "sy_action_mask_dense", "sy_belief_update", "sy_build_apsp", "sy_sample_boards",
+           "sy_env_step", "sy_env_step_record", "sy_env_rollout", "sy_action_mask_dense", "sy_belief_update", "sy_build_apsp", "sy_sample_boards",
            "sy_masked_categorical_sample"]
 
 _lib = None
@@ -66,6 +66,7 @@ def load():
     lib.sy_env_reset.argtypes = [vp, vp, u64, vp]
     lib.sy_env_reset_to.argtypes = [vp, vp, vp]
     lib.sy_env_step.argtypes = [vp, vp, vp]
+    lib.sy_env_step_record.argtypes = [vp, vp, C.POINTER(RolloutBuffers), vp]
     lib.sy_env_rollout.argtypes = [vp, i32, C.POINTER(RolloutBuffers), vp]
     lib.sy_action_mask_dense.argtypes = [vp, vp, vp, i32, vp, vp, i32, vp, vp]
     lib.sy_belief_update.argtypes = [vp, vp, i32, i32, vp, vp, i32, vp, i32, vp]

@@ -187,28 +187,16 @@ class RolloutCollector:
     def _policy_loop(self):
         env, T, buf = self.env, self.T, self._buf
         for s in range(T):
-            obs = env.observation()
-            buf["pos"][s].copy_(env.pos)
-            buf["budget"][s].copy_(env.budget)
-            buf["t"][s].copy_(env.t)
-            if buf["mask"] is not None:
-                buf["mask"][s].copy_(env._mask)
-            if buf["belief"] is not None:
-                buf["belief"][s].copy_(env._belief)
-            actions, logp, value = self.policy(obs)
+            actions, logp, value = self.policy(env.observation())
             actions = actions.to(torch.int32).contiguous()
-            buf["action"][s].copy_(actions)
             if logp is not None:
                 self._logp[s].copy_(logp)
             if value is not None:
                 if self._value is None:
                     self._value = torch.zeros((T,) + tuple(value.shape), dtype=torch.float32, device=env.device)
                 self._value[s].copy_(value)
-            env.step(actions)
-            buf["reward"][s].copy_(env.reward)
-            buf["terminated"][s].copy_(env._terminated)
-            buf["truncated"][s].copy_(env._truncated)
-            buf["winner"][s].copy_(env.winner)
+            # one kernel: the transition plus row s of the record (observation before the step, action, outcome)
+            env.step_record(actions, buf, s)
 
     @torch.no_grad()
     def collect(self) -> Dict[str, torch.Tensor]:

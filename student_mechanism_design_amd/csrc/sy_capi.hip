@@ -193,6 +193,17 @@ int sy_env_step(sy_env* env, const int32_t* actions, void* stream) {
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_env_step launch");
 }
 
+int sy_env_step_record(sy_env* env, const int32_t* actions, const sy_rollout_buffers* row, void* stream) {
+    int rc = ready(env, "sy_env_step_record");
+    if (rc) return rc;
+    if (!env->has_rewards) return fail(SY_ERR_STATE, "%s: call sy_env_set_rewards first", "sy_env_step_record");
+    if (!actions || !row) return fail(SY_ERR_INVALID, "sy_env_step_record: null argument%s");
+    if ((reinterpret_cast<uintptr_t>(row->mask) & 15) || (reinterpret_cast<uintptr_t>(row->record) & 15))
+        return fail(SY_ERR_INVALID, "sy_env_step_record: record / mask rows must be 16-byte aligned%s");
+    hipError_t e = sy::launch_engine(env->p, actions, 1, *row, true, env->blocks, env->wpb, env->lds, (hipStream_t)stream);
+    return e == hipSuccess ? SY_OK : hip_fail(e, "sy_env_step_record launch");
+}
+
 int sy_env_rollout(sy_env* env, int32_t T, const sy_rollout_buffers* out, void* stream) {
     int rc = ready(env, "sy_env_rollout");
     if (rc) return rc;

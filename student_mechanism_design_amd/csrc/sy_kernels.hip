@@ -733,8 +733,12 @@ __device__ __forceinline__ void stage_block(const EngineParams& p, const LdsMap&
 // ---------------------------------------------------------------------------------------------
 // step_kernel: one env transition with caller-given actions (sy_env_step), one wave per episode.
 // ---------------------------------------------------------------------------------------------
+// `rec` (sy_env_step_record): the row of a rollout record this transition fills — the observation before
+// the step (masks, belief), the packed {reward, pos, budget, action, t, flags} row — so a policy-driven
+// collector needs no copy kernels.  All three pointers may be null.
 template <int NR>
-__global__ __launch_bounds__(1024) void step_kernel(const EngineParams p, const int32_t* __restrict__ actions) {
+__global__ __launch_bounds__(1024) void step_kernel(const EngineParams p, const int32_t* __restrict__ actions,
+                                                    const sy_rollout_buffers rec) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wpb = blockDim.x >> 6;
     const int N = p.N, NS = p.NS, A = p.A, P = p.P, B = p.B;
@@ -769,6 +773,17 @@ __global__ __launch_bounds__(1024) void step_kernel(const EngineParams p, const 
     int slab_w[NR];
     if (has_belief) belief_load<NR>(b, ideg, slab_w, p.st.belief + (size_t)e * NS, p.inv_deg + (size_t)g * NS, lane, N);
 
+    const int pos0_v = pos_v, mon0_v = mon_v, t0 = t;
+    if (rec.mask) {        // the pre-step masks are the state's
+        const uint4* src = reinterpret_cast<const uint4*>(p.st.mask + (size_t)e * A * NS);
+        uint4* dst = reinterpret_cast<uint4*>(rec.mask + (size_t)e * A * NS);
+        for (int i = lane; i < n16; i += kWave) dst[i] = src[i];
+    }
+    if (rec.belief && has_belief) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (lane + 64 * r < NS) rec.belief[(size_t)e * NS + lane + 64 * r] = b[r];
+    }
     bool ok_v;
     int cost_v;
     scan_hits(L.ell_s, lane, A, p.scan_w, sm, pos_v, mon_v, act_v, ok_v, cost_v);
@@ -815,6 +830,17 @@ __global__ __launch_bounds__(1024) void step_kernel(const EngineParams p, const 
         p.st.terminated[e] = (uint8_t)term;
         p.st.truncated[e] = (uint8_t)trunc;
         p.st.winner[e] = (int8_t)win;
+    }
+    if (rec.record) {      // the packed row, same layout as the fused rollout's
+        const int RW = p.rec_words;
+        int* rdst = rec.record + (size_t)e * RW;
+        if (lane < A) {
+            *reinterpret_cast<double*>(rdst + 2 * lane) = rew;
+            rdst[2 * A + lane] = pos0_v;
+            rdst[3 * A + lane] = mon0_v;
+            rdst[4 * A + lane] = act_v;
+        }
+        if (lane < RW - 5 * A) rdst[5 * A + lane] = lane == 0 ? t0 : (lane == 1 ? term : (lane == 2 ? trunc : (lane == 3 ? win : 0)));
     }
     if (ended && p.auto_reset) {
         const int st = sample_starts(lane, A, N, p.env_id_offset + (uint64_t)e, sc, p.seed_lo, p.seed_hi);
@@ -2275,7 +2301,7 @@ template <int NR>
 static hipError_t launch_engine_nr(const EngineParams& p, const int32_t* actions, int T, const sy_rollout_buffers& out,
                                    bool ext, int blocks, int wpb, size_t lds, hipStream_t stream) {
     if (ext) {
-        hipLaunchKernelGGL((step_kernel<NR>), dim3(blocks), dim3(wpb * 64), lds, stream, p, actions);
+        hipLaunchKernelGGL((step_kernel<NR>), dim3(blocks), dim3(wpb * 64), lds, stream, p, actions, out);
     } else {
         const bool paired = (wpb & 1) == 0;            // paired move waves need an even number of episodes per block
         const int threads = paired ? 64 * (wpb / 2 + (p.st.belief ? wpb / 2 : 0))

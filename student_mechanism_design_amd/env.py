@@ -221,6 +221,25 @@ class BatchedScotlandYardEnv:
             _lib.check(self.lib.sy_env_step(self._handle, _ptr(act), _stream_handle(self.device)), "sy_env_step")
         return self.observation(), self.reward, self.terminated, self.truncated
 
+    def step_record(self, actions: torch.Tensor, out: Dict[str, torch.Tensor], s: int):
+        """`step` that also fills row `s` of a rollout record from `alloc_rollout` (observation before the
+        step, packed outcome row) inside the same kernel: no copy launches in a policy-driven collector."""
+        act = actions
+        if not (isinstance(act, torch.Tensor) and act.dtype == torch.int32 and act.is_contiguous()
+                and act.device == self.device):
+            act = torch.as_tensor(actions).to(device=self.device, dtype=torch.int32).contiguous()
+        if tuple(act.shape) != (self.B, self.A):
+            raise ValueError(f"actions must have shape ({self.B}, {self.A})")
+        if not 0 <= s < out["record"].shape[0]:
+            raise IndexError("record row out of range")
+        row = _lib.RolloutBuffers(out["record"][s].data_ptr(),
+                                  out["mask"][s].data_ptr() if out.get("mask") is not None else None,
+                                  out["belief"][s].data_ptr() if out.get("belief") is not None else None)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.sy_env_step_record(self._handle, _ptr(act), C.byref(row), _stream_handle(self.device)),
+                       "sy_env_step_record")
+        return self.observation(), self.reward, self.terminated, self.truncated
+
     def alloc_rollout(self, T: int, record_mask=True, record_belief=True) -> Dict[str, torch.Tensor]:
         """Device buffers of one rollout.  `record` is the packed [T, B, RW] int32 tensor the engine
         writes with one store per env-step (include/sy_env.h); the named entries are views of it."""

@@ -346,3 +346,45 @@ def test_device_masked_sampler_against_the_reference_goldens(sy):
         ai = int(a[0])
         assert ref_norm[ai] > 0 and (c["kind"] == "empty_mask" or c["mask"][ai] == 1)
         np.testing.assert_allclose(float(logp[0]), np.log(ref_norm[ai]), rtol=1e-4, atol=1e-5)
+
+
+def test_step_record_fills_the_row_the_collector_used_to_copy(sy):
+    """sy_env_step_record: one kernel for the transition and row s of the rollout record.  A twin env
+    stepped with plain step() and explicit copies must produce the same record, bit for bit."""
+    N, P, B, T = 70, 4, 53, 25
+    boards = sy.sample_board_pool(2, N, 120, seed=6)
+    w = np.linspace(0.2, 0.8, 11)
+    a = sy.BatchedScotlandYardEnv(B, boards, P, 9, w, seed=3, reveal_interval=3, max_timestep=12)
+    b = sy.BatchedScotlandYardEnv(B, boards, P, 9, w, seed=3, reveal_interval=3, max_timestep=12)
+    buf = a.alloc_rollout(T)
+    ref = b.alloc_rollout(T)
+    rng = np.random.default_rng(0)
+    for s in range(T):
+        mask = _np(a._mask)[..., :N]
+        act = np.full((B, P + 1), -1, dtype=np.int32)
+        for e in range(B):
+            for k in range(P + 1):
+                legal = np.nonzero(mask[e, k])[0]
+                if legal.size and rng.random() < 0.85:
+                    act[e, k] = rng.choice(legal)
+                elif rng.random() < 0.3:
+                    act[e, k] = rng.integers(0, N)          # possibly illegal: the agent stays
+        act_t = torch.as_tensor(act, device=a.device)
+        for k in ("pos", "budget", "t"):
+            ref[k][s].copy_(getattr(b, k))
+        ref["mask"][s].copy_(b._mask)
+        ref["belief"][s].copy_(b._belief)
+        ref["action"][s].copy_(act_t)
+        a.step_record(act_t, buf, s)
+        b.step(act_t)
+        ref["reward"][s].copy_(b.reward)
+        ref["terminated"][s].copy_(b._terminated)
+        ref["truncated"][s].copy_(b._truncated)
+        ref["winner"][s].copy_(b.winner)
+    torch.cuda.synchronize()
+    for k in ("record", "mask", "belief"):
+        np.testing.assert_array_equal(_np(buf[k]), _np(ref[k]), err_msg=k)
+    assert bool((buf["terminated"] | buf["truncated"]).any())
+    np.testing.assert_array_equal(_np(a.pos), _np(b.pos))
+    a.close()
+    b.close()

@@ -169,6 +169,24 @@ int sy_masked_categorical_sample(const float *probs, int64_t probs_row_stride, c
                                  const uint64_t *offset_dev, int32_t default_on_empty, int32_t *action, float *log_prob,
                                  float *norm_probs, void *stream);
 
+/* The MAPPO networks' parameters, all device float32, laid out for the kernel: first actor layers transposed
+ * w1t [A][N][H] (torch Linear weight [H][N] transposed), b1 [A][H]; second actor layers transposed w2t [A][H][N],
+ * b2 [A][N]; critic first layer transposed c1t [N*A][H], cb1 [H], second layer c2 [H], cb2 [1] (critic may be NULL
+ * when no value is requested). */
+typedef struct sy_mappo_weights {
+    const float *w1t, *b1, *w2t, *b2, *c1t, *cb1, *c2, *cb2;
+} sy_mappo_weights;
+
+/* replaces MappoAgent.select_action for every (env, agent) in one launch (agent/mappo_agent.py:6-44,87-142):
+ * actor MLPs on the trainer's observations (one-hot MrX node / multi-hot police nodes, mappo_trainer.py:173,197),
+ * masked sampling as in sy_masked_categorical_sample (an empty mask gives action -1), and the central critic on
+ * [mrx] + [police] * P.  pos int32 [B][A], mask uint8 [B][A][mask_row_stride]; outputs action int32 [B][A],
+ * log_prob float [B][A], value float [B] (NULL = skip the critic), probs float [B][A][N] (NULL = not wanted: the
+ * actor's softmax before masking).  hidden <= 64. */
+int sy_mappo_policy_act(const int32_t *pos, const uint8_t *mask, int64_t mask_row_stride, const sy_mappo_weights *w,
+                        int32_t num_envs, int32_t num_police, int32_t num_nodes, int32_t hidden, uint64_t seed, uint64_t offset,
+                        const uint64_t *offset_dev, int32_t *action, float *log_prob, float *value, float *probs, void *stream);
+
 /* replaces Pathfinder.get_distance (pathfinding.py:34-137) for a whole pool: all-pairs weighted
  * shortest paths from the ELL table, apsp uint16 [G][N][N] (0xFFFF = unreachable); all device */
 int sy_build_apsp(const uint32_t *ell, int32_t num_nodes, int32_t num_graphs, uint16_t *apsp, void *stream);

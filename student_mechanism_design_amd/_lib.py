@@ -31,6 +31,10 @@ class EnvState(C.Structure):
                                           "reward", "terminated", "truncated", "winner")]
 
 
+class MappoWeights(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("w1t", "b1", "w2t", "b2", "c1t", "cb1", "c2", "cb2")]
+
+
 class RolloutBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("record", "mask", "belief")]
 
@@ -38,7 +42,7 @@ class RolloutBuffers(C.Structure):
 EXPORTS = ["sy_abi_version", "sy_record_words", "sy_last_error", "sy_env_create", "sy_env_destroy", "sy_env_launch_info",
            "sy_env_set_graph_pool", "sy_env_set_rewards", "sy_env_bind_state", "sy_env_reset", "sy_env_reset_to",
            "sy_env_step", "sy_env_step_record", "sy_env_rollout", "sy_action_mask_dense", "sy_belief_update", "sy_build_apsp", "sy_sample_boards",
-           "sy_masked_categorical_sample"]
+           "sy_masked_categorical_sample", "sy_mappo_policy_act"]
 
 _lib = None
 
@@ -73,6 +77,7 @@ def load():
     lib.sy_build_apsp.argtypes = [vp, i32, i32, vp, vp]
     lib.sy_sample_boards.argtypes = [i32, i32, i32, i32, u64, i32, vp, vp, vp, vp, vp, i32, vp]
     lib.sy_masked_categorical_sample.argtypes = [vp, C.c_int64, vp, C.c_int64, i32, i32, u64, u64, vp, i32, vp, vp, vp, vp]
+    lib.sy_mappo_policy_act.argtypes = [vp, vp, C.c_int64, C.POINTER(MappoWeights), i32, i32, i32, i32, u64, u64, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("sy_last_error",):

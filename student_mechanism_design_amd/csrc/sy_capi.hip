@@ -258,6 +258,24 @@ int sy_masked_categorical_sample(const float* probs, int64_t probs_row_stride, c
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_masked_categorical_sample launch");
 }
 
+int sy_mappo_policy_act(const int32_t* pos, const uint8_t* mask, int64_t mask_row_stride, const sy_mappo_weights* w,
+                        int32_t num_envs, int32_t num_police, int32_t num_nodes, int32_t hidden, uint64_t seed, uint64_t offset,
+                        const uint64_t* offset_dev, int32_t* action, float* log_prob, float* value, float* probs, void* stream) {
+    if (!pos || !mask || !w || !action || !log_prob) return fail(SY_ERR_INVALID, "sy_mappo_policy_act: null argument%s");
+    if (!w->w1t || !w->b1 || !w->w2t || !w->b2) return fail(SY_ERR_INVALID, "sy_mappo_policy_act: null actor weights%s");
+    if (value && (!w->c1t || !w->cb1 || !w->c2 || !w->cb2)) return fail(SY_ERR_INVALID, "sy_mappo_policy_act: null critic weights%s");
+    if (num_police < 1 || num_police > SY_MAX_AGENTS - 1 || num_nodes < 1 || num_nodes > SY_MAX_NODES || mask_row_stride < num_nodes)
+        return fail(SY_ERR_INVALID, "sy_mappo_policy_act: bad sizes%s");
+    if (hidden < 1 || hidden > 64) return fail(SY_ERR_INVALID, "sy_mappo_policy_act: hidden size must be in [1, 64]%s");
+    if ((size_t)hidden * num_nodes * sizeof(float) > kMaxLds) return fail(SY_ERR_INVALID, "sy_mappo_policy_act: layer does not fit in LDS%s");
+    if (num_envs < 0) return fail(SY_ERR_INVALID, "sy_mappo_policy_act: bad num_envs%s");
+    if (num_envs == 0) return SY_OK;
+    hipError_t e = sy::launch_mappo_policy(pos, mask, mask_row_stride, w->w1t, w->b1, w->w2t, w->b2, w->c1t, w->cb1, w->c2, w->cb2,
+                                           num_envs, num_police + 1, num_nodes, hidden, seed, offset, offset_dev, action, log_prob,
+                                           value, probs, (hipStream_t)stream);
+    return e == hipSuccess ? SY_OK : hip_fail(e, "sy_mappo_policy_act launch");
+}
+
 int sy_build_apsp(const uint32_t* ell, int32_t num_nodes, int32_t num_graphs, uint16_t* apsp, void* stream) {
     if (!ell || !apsp) return fail(SY_ERR_INVALID, "sy_build_apsp: null argument%s");
     if (num_nodes < 1 || num_nodes > SY_MAX_NODES || num_graphs < 1) return fail(SY_ERR_INVALID, "sy_build_apsp: bad sizes%s");

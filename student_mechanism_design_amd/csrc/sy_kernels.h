@@ -51,4 +51,10 @@ hipError_t launch_masked_sample(const float* probs, long long probs_stride, cons
                                 int rows, int N, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                                 int default_on_empty, int32_t* action, float* log_prob, float* norm_out, hipStream_t stream);
 
+hipError_t launch_mappo_policy(const int32_t* pos, const uint8_t* mask, long long mask_row_stride, const float* w1t,
+                               const float* b1, const float* w2t, const float* b2, const float* c1t, const float* cb1,
+                               const float* c2, const float* cb2, int B, int A, int N, int H, uint64_t seed, uint64_t offset,
+                               const uint64_t* offset_dev, int32_t* action, float* log_prob, float* value, float* probs_out,
+                               hipStream_t stream);
+
 }  // namespace sy

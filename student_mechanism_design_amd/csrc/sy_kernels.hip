@@ -2216,25 +2216,20 @@ __device__ __forceinline__ float wave_incl_scan(float v, int lane) {   // inclus
     return v + (row == 0 ? 0.0f : (row == 1 ? r0 : (row == 2 ? r0 + r1 : (r0 + r1) + r2)));
 }
 
+// The sampling core shared by masked_sample_kernel and mappo_policy_kernel: pr[] = the actor's
+// probabilities of nodes lane + 64 r (0 past N), mr = the row's mask bytes.
 template <int NR>
-__global__ __launch_bounds__(256) void masked_sample_kernel(const float* __restrict__ probs, long long probs_stride,
-                                                            const uint8_t* __restrict__ mask, long long mask_stride, int rows,
-                                                            int N, uint32_t seed_lo, uint32_t seed_hi, uint64_t offset_imm,
-                                                            const uint64_t* __restrict__ offset_dev,
-                                                            int default_on_empty, int32_t* __restrict__ action,
-                                                            float* __restrict__ log_prob, float* __restrict__ norm_out) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* pr = probs + (size_t)row * probs_stride;
-    const uint8_t* mr = mask + (size_t)row * mask_stride;
+__device__ __forceinline__ void masked_sample_row(const float (&pr)[NR], const uint8_t* __restrict__ mr, int lane, int N,
+                                                  uint64_t stream_row, uint32_t seed_lo, uint32_t seed_hi, uint64_t offset,
+                                                  int default_on_empty, int32_t* action_out, float* logp_out,
+                                                  float* norm_row) {
     float pv[NR], mv[NR];
     float s_loc = 0.0f, m_loc = 0.0f;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
         const int j = lane + 64 * r;
         mv[r] = (j < N && mr[j]) ? 1.0f : 0.0f;
-        pv[r] = j < N ? pr[j] * mv[r] : 0.0f;
+        pv[r] = j < N ? pr[r] * mv[r] : 0.0f;
         s_loc += pv[r];
         m_loc += mv[r];
     }
@@ -2252,10 +2247,8 @@ __global__ __launch_bounds__(256) void masked_sample_kernel(const float* __restr
     }
     const float total = wave_sum(t_loc);
     const float inv_t = 1.0f / total;
-    // the draw; a device-resident offset lets a captured HIP graph advance the stream between replays
-    const uint64_t offset = offset_imm + (offset_dev ? *offset_dev : 0ull);
     uint32_t o[4];
-    philox4((uint64_t)row, (uint32_t)offset, 3u, (uint32_t)(offset >> 32) & 0xffu, seed_lo, seed_hi, o);
+    philox4(stream_row, (uint32_t)offset, 3u, (uint32_t)(offset >> 32) & 0xffu, seed_lo, seed_hi, o);
     const float u = (float)(o[0] >> 8) * (1.0f / 16777216.0f);
     float base = 0.0f;
     int found = 0x7fffffff;
@@ -2264,7 +2257,7 @@ __global__ __launch_bounds__(256) void masked_sample_kernel(const float* __restr
     for (int r = 0; r < NR; ++r) {
         const int j = lane + 64 * r;
         const float nv = pv[r] * inv_t;                       // Categorical's renormalised probability
-        if (norm_out && j < N) norm_out[(size_t)row * N + j] = nv;
+        if (norm_row && j < N) norm_row[j] = nv;
         const float incl = base + wave_incl_scan(nv, lane);
         if (nv > 0.0f && incl > u && j < found) { found = j; p_found = nv; }
         base = __int_as_float(rdlane(__float_as_int(incl), 63));
@@ -2289,9 +2282,133 @@ __global__ __launch_bounds__(256) void masked_sample_kernel(const float* __restr
     const float pa_mine = (found == a) ? p_found : ((last_pos == a && best == 0x7fffffff) ? p_last : 0.0f);
     const float pa = wave_sum(pa_mine);                          // exactly one lane holds it
     if (lane == 0) {
-        action[row] = (empty && default_on_empty) ? -1 : a;
-        log_prob[row] = logf(pa);
+        *action_out = (empty && default_on_empty) ? -1 : a;
+        *logp_out = logf(pa);
     }
+}
+
+template <int NR>
+__global__ __launch_bounds__(256) void masked_sample_kernel(const float* __restrict__ probs, long long probs_stride,
+                                                            const uint8_t* __restrict__ mask, long long mask_stride, int rows,
+                                                            int N, uint32_t seed_lo, uint32_t seed_hi, uint64_t offset_imm,
+                                                            const uint64_t* __restrict__ offset_dev,
+                                                            int default_on_empty, int32_t* __restrict__ action,
+                                                            float* __restrict__ log_prob, float* __restrict__ norm_out) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* prow = probs + (size_t)row * probs_stride;
+    float pr[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) pr[r] = lane + 64 * r < N ? prow[lane + 64 * r] : 0.0f;
+    // a device-resident offset lets a captured HIP graph advance the stream between replays
+    const uint64_t offset = offset_imm + (offset_dev ? *offset_dev : 0ull);
+    masked_sample_row<NR>(pr, mask + (size_t)row * mask_stride, lane, N, (uint64_t)row, seed_lo, seed_hi, offset,
+                          default_on_empty, action + row, log_prob + row, norm_out ? norm_out + (size_t)row * N : nullptr);
+}
+
+// ---------------------------------------------------------------------------------------------
+// mappo_policy_kernel: MappoAgent.select_action for every (env, agent) in ONE launch — the actor MLPs
+// (AgentPolicy, agent/mappo_agent.py:6-29: Linear -> ReLU -> Linear -> softmax on the trainer's
+// observations, mappo_trainer.py:173,197: one-hot MrX node for MrX, multi-hot police nodes for the
+// police), the masked sampling (:112-142), and the central critic (CentralCritic, :32-44, on
+// [mrx] + [police] * P).  A one-hot input makes the first layer a row lookup in its transposed
+// weight; the second layer's transposed weight of the block's agent is staged once in LDS and each
+// wave runs one row's 64-term dot products against it.  grid.y = agent (A = the critic's blocks).
+// ---------------------------------------------------------------------------------------------
+struct MappoWeights {
+    const float* w1t;   // [A][N][H]   first actor layers, transposed
+    const float* b1;    // [A][H]
+    const float* w2t;   // [A][H][N]   second actor layers, transposed
+    const float* b2;    // [A][N]
+    const float* c1t;   // [N * A][H]  first critic layer, transposed
+    const float* cb1;   // [H]
+    const float* c2;    // [H]         second critic layer
+    const float* cb2;   // [1]
+};
+
+template <int NR>
+__global__ __launch_bounds__(1024) void mappo_policy_kernel(const int32_t* __restrict__ pos, const uint8_t* __restrict__ mask,
+                                                            long long mask_row_stride, const MappoWeights w, int B, int A, int N,
+                                                            int H, uint32_t seed_lo, uint32_t seed_hi, uint64_t offset_imm,
+                                                            const uint64_t* __restrict__ offset_dev, int32_t* __restrict__ action,
+                                                            float* __restrict__ log_prob, float* __restrict__ value,
+                                                            float* __restrict__ probs_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* w2s = reinterpret_cast<float*>(smem);                 // [H][N] of this block's agent
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    const int a = blockIdx.y;
+    const int b = blockIdx.x * wpb + wid;
+    const int P = A - 1;
+    if (a < A) {
+        const float* src = w.w2t + (size_t)a * H * N;
+        for (int i = threadIdx.x; i < H * N; i += blockDim.x) w2s[i] = src[i];
+        __syncthreads();
+    }
+    if (b >= B) return;
+    const int32_t* prow = pos + (size_t)b * A;
+    if (a == A) {
+        // ---- central critic: h = relu(cb1 + C1t[mrx] + sum_k sum_j C1t[N (1 + k) + police_j]), value = c2 . h + cb2
+        if (!value) return;
+        float h = lane < H ? w.cb1[lane] : 0.0f;
+        if (lane < H) {
+            h += w.c1t[(size_t)prow[0] * H + lane];
+            for (int k = 0; k < P; ++k)
+                for (int j = 0; j < P; ++j) h += w.c1t[((size_t)N * (1 + k) + prow[1 + j]) * H + lane];
+        }
+        h = h > 0.0f ? h : 0.0f;
+        const float v = wave_sum(lane < H ? h * w.c2[lane] : 0.0f) + w.cb2[0];
+        if (lane == 0) value[b] = v;
+        return;
+    }
+    // ---- actor a: first layer by row lookups (lane k holds hidden unit k)
+    float h = lane < H ? w.b1[(size_t)a * H + lane] : 0.0f;
+    if (lane < H) {
+        const float* w1a = w.w1t + (size_t)a * N * H;
+        if (a == 0) h += w1a[(size_t)prow[0] * H + lane];
+        else
+            for (int j = 0; j < P; ++j) h += w1a[(size_t)prow[1 + j] * H + lane];
+    }
+    h = h > 0.0f ? h : 0.0f;
+    // second layer: logits[n] = b2[n] + sum_k h[k] W2t[k][n], n = lane + 64 r, weights from LDS
+    float acc[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) acc[r] = lane + 64 * r < N ? w.b2[(size_t)a * N + lane + 64 * r] : 0.0f;
+    const int hi = __float_as_int(h);
+    for (int k = 0; k < H; ++k) {
+        const float hk = __int_as_float(__builtin_amdgcn_readlane(hi, k));
+        const float* wk = w2s + k * N;
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (lane + 64 * r < N) acc[r] = fmaf(hk, wk[lane + 64 * r], acc[r]);
+    }
+    // softmax over the N nodes
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) mx = (lane + 64 * r < N && acc[r] > mx) ? acc[r] : mx;
+#pragma unroll
+    for (int o2 = 32; o2 >= 1; o2 >>= 1) {
+        const float om = __shfl_xor(mx, o2, kWave);
+        mx = om > mx ? om : mx;
+    }
+    float pr[NR], se = 0.0f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        pr[r] = lane + 64 * r < N ? __expf(acc[r] - mx) : 0.0f;
+        se += pr[r];
+    }
+    const float inv = 1.0f / wave_sum(se);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) pr[r] *= inv;
+    const size_t row = (size_t)b * A + a;
+    if (probs_out) {
+#pragma unroll
+        for (int r = 0; r < NR; ++r)
+            if (lane + 64 * r < N) probs_out[row * N + lane + 64 * r] = pr[r];
+    }
+    const uint64_t offset = offset_imm + (offset_dev ? *offset_dev : 0ull);
+    masked_sample_row<NR>(pr, mask + row * mask_row_stride, lane, N, (uint64_t)row, seed_lo, seed_hi, offset, 1, action + row,
+                          log_prob + row, nullptr);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2419,6 +2536,29 @@ hipError_t launch_masked_sample(const float* probs, long long probs_stride, cons
     else if (nr <= 8) SY_LAUNCH_MS(8);
     else SY_LAUNCH_MS(16);
 #undef SY_LAUNCH_MS
+    return hipGetLastError();
+}
+
+hipError_t launch_mappo_policy(const int32_t* pos, const uint8_t* mask, long long mask_row_stride, const float* w1t,
+                               const float* b1, const float* w2t, const float* b2, const float* c1t, const float* cb1,
+                               const float* c2, const float* cb2, int B, int A, int N, int H, uint64_t seed, uint64_t offset,
+                               const uint64_t* offset_dev, int32_t* action, float* log_prob, float* value, float* probs_out,
+                               hipStream_t stream) {
+    MappoWeights w{w1t, b1, w2t, b2, c1t, cb1, c2, cb2};
+    const int wpb = 16;
+    const dim3 grid((B + wpb - 1) / wpb, A + (value ? 1 : 0));
+    const size_t lds = (size_t)H * N * sizeof(float);
+    const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
+    const int nr = (N + 63) / 64;
+#define SY_LAUNCH_MP(NR_) hipLaunchKernelGGL((mappo_policy_kernel<NR_>), grid, dim3(wpb * 64), lds, stream, pos, mask,        \
+                                             mask_row_stride, w, B, A, N, H, lo, hi, offset, offset_dev, action, log_prob,   \
+                                             value, probs_out)
+    if (nr <= 1) SY_LAUNCH_MP(1);
+    else if (nr <= 2) SY_LAUNCH_MP(2);
+    else if (nr <= 4) SY_LAUNCH_MP(4);
+    else if (nr <= 8) SY_LAUNCH_MP(8);
+    else SY_LAUNCH_MP(16);
+#undef SY_LAUNCH_MP
     return hipGetLastError();
 }
 

@@ -107,6 +107,75 @@ class MappoPolicy(nn.Module):
         return a, logp, self.value_fast(obs)
 
 
+class DeviceMappoPolicy:
+    """`MappoPolicy.act` as ONE HIP kernel (`sy_mappo_policy_act`, include/sy_env.h): actor MLPs on the
+    trainer's observations, masked sampling, central critic — MappoAgent.select_action for every
+    (env, agent) of the batch in a single launch.  The first layers are row lookups in transposed weights, the
+    second layers run from LDS; draws come from the engine's Philox stream with a device-resident call
+    counter (fresh numbers on every replay of a captured HIP graph).  Call `refresh()` after the wrapped
+    module's parameters change.  Fails loudly without the engine library / a GPU."""
+
+    def __init__(self, net: "MappoPolicy", seed: int = 0):
+        from . import _lib
+        self._lib_mod, self.lib, self.net = _lib, _lib.load(), net
+        self.device = next(net.parameters()).device
+        if self.device.type != "cuda":
+            raise _lib.EngineError("DeviceMappoPolicy needs the module on a GPU; there is no CPU fallback")
+        self.H = net.actors[0][0].out_features
+        if self.H > 64:
+            raise ValueError("hidden size above 64 is not supported by the fused kernel")
+        self.seed = int(seed) & (2**64 - 1)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self._out = None
+        self.refresh()
+
+    @torch.no_grad()
+    def refresh(self):
+        """Re-pack the module's parameters in the kernel's layout (after every optimiser step)."""
+        f32 = dict(dtype=torch.float32, device=self.device)
+        acts = self.net.actors
+        self.w1t = torch.stack([a[0].weight.t() for a in acts]).to(**f32).contiguous()       # [A, N, H]
+        self.b1 = torch.stack([a[0].bias for a in acts]).to(**f32).contiguous()              # [A, H]
+        self.w2t = torch.stack([a[2].weight.t() for a in acts]).to(**f32).contiguous()       # [A, H, N]
+        self.b2 = torch.stack([a[2].bias for a in acts]).to(**f32).contiguous()              # [A, N]
+        self.c1t = self.net.critic[0].weight.t().to(**f32).contiguous()                      # [N * A, H]
+        self.cb1 = self.net.critic[0].bias.to(**f32).contiguous()
+        self.c2 = self.net.critic[2].weight.reshape(-1).to(**f32).contiguous()               # [H]
+        self.cb2 = self.net.critic[2].bias.to(**f32).contiguous()
+        import ctypes as C
+        self._w = self._lib_mod.MappoWeights(*[C.c_void_p(t.data_ptr()) for t in (
+            self.w1t, self.b1, self.w2t, self.b2, self.c1t, self.cb1, self.c2, self.cb2)])
+
+    @torch.no_grad()
+    def act(self, obs: Dict[str, torch.Tensor], want_probs: bool = False):
+        """Collector callback: (actions int32 [B, A], log_prob [B, A], value [B]); with want_probs a 4th item,
+        the actors' softmax [B, A, N]."""
+        import ctypes as C
+        pos, mask = obs["agent_position"], obs["action_mask"]
+        B, A = pos.shape
+        N = self.net.N
+        if pos.dtype != torch.int32 or not pos.is_contiguous():
+            pos = pos.to(torch.int32).contiguous()
+        mk = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+        if mk.stride(-1) != 1 or mk.stride(0) != A * mk.stride(1):     # rows may be padded (the engine's NS), not scattered
+            mk = mk.contiguous()
+        if self._out is None or self._out[0].shape[0] != B:
+            self._out = (torch.empty((B, A), dtype=torch.int32, device=self.device),
+                         torch.empty((B, A), dtype=torch.float32, device=self.device),
+                         torch.empty((B,), dtype=torch.float32, device=self.device))
+        act, logp, val = self._out
+        probs = torch.empty((B, A, N), dtype=torch.float32, device=self.device) if want_probs else None
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):
+            self._lib_mod.check(self.lib.sy_mappo_policy_act(
+                C.c_void_p(pos.data_ptr()), C.c_void_p(mk.data_ptr()), C.c_int64(mk.stride(1)), C.byref(self._w),
+                B, A - 1, N, self.H, C.c_uint64(self.seed), C.c_uint64(0), C.c_void_p(self.counter.data_ptr()),
+                C.c_void_p(act.data_ptr()), C.c_void_p(logp.data_ptr()), C.c_void_p(val.data_ptr()),
+                C.c_void_p(probs.data_ptr()) if probs is not None else None, stream), "sy_mappo_policy_act")
+        self.counter.add_(1)
+        return (act, logp, val, probs) if want_probs else (act, logp, val)
+
+
 class AntiSymmetricConvDense(nn.Module):
     def __init__(self, channels: int, epsilon: float = 0.1, gamma: float = 0.1):
         super().__init__()

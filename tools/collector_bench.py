@@ -22,11 +22,15 @@ env.reset(seed=1)
 pol = MappoPolicy(N, P).to(env.device)
 from student_mechanism_design_amd.collector import DeviceMaskedSampler  # noqa: E402
 smp = DeviceMaskedSampler(env.device, seed=7)
+from student_mechanism_design_amd.policies import DeviceMappoPolicy  # noqa: E402
+fused = DeviceMappoPolicy(pol, seed=7)
 for use_graph, fn, name in ((False, pol.act, "reference-shaped forward, torch sampling"),
                             (True, pol.act, "reference-shaped forward, torch sampling"),
                             (True, pol.act_fast, "lookup + batched-matmul forward, torch sampling"),
                             (False, lambda obs: pol.act_device(obs, smp), "lookup + batched-matmul forward, HIP sampling kernel"),
-                            (True, lambda obs: pol.act_device(obs, smp), "lookup + batched-matmul forward, HIP sampling kernel")):
+                            (True, lambda obs: pol.act_device(obs, smp), "lookup + batched-matmul forward, HIP sampling kernel"),
+                            (False, fused.act, "fused HIP policy kernel (actors + sampling + critic)"),
+                            (True, fused.act, "fused HIP policy kernel (actors + sampling + critic)")):
     col = RolloutCollector(env, fn, frames_per_batch=T, use_graph=use_graph)
     col.collect()
     col.collect()          # (graph mode: capture + first replay)

@@ -267,7 +267,6 @@ int sy_mappo_policy_act(const int32_t* pos, const uint8_t* mask, int64_t mask_ro
     if (num_police < 1 || num_police > SY_MAX_AGENTS - 1 || num_nodes < 1 || num_nodes > SY_MAX_NODES || mask_row_stride < num_nodes)
         return fail(SY_ERR_INVALID, "sy_mappo_policy_act: bad sizes%s");
     if (hidden < 1 || hidden > 64) return fail(SY_ERR_INVALID, "sy_mappo_policy_act: hidden size must be in [1, 64]%s");
-    if ((size_t)hidden * num_nodes * sizeof(float) > kMaxLds) return fail(SY_ERR_INVALID, "sy_mappo_policy_act: layer does not fit in LDS%s");
     if (num_envs < 0) return fail(SY_ERR_INVALID, "sy_mappo_policy_act: bad num_envs%s");
     if (num_envs == 0) return SY_OK;
     hipError_t e = sy::launch_mappo_policy(pos, mask, mask_row_stride, w->w1t, w->b1, w->w2t, w->b2, w->c1t, w->cb1, w->c2, w->cb2,

@@ -2313,8 +2313,9 @@ __global__ __launch_bounds__(256) void masked_sample_kernel(const float* __restr
 // observations, mappo_trainer.py:173,197: one-hot MrX node for MrX, multi-hot police nodes for the
 // police), the masked sampling (:112-142), and the central critic (CentralCritic, :32-44, on
 // [mrx] + [police] * P).  A one-hot input makes the first layer a row lookup in its transposed
-// weight; the second layer's transposed weight of the block's agent is staged once in LDS and each
-// wave runs one row's 64-term dot products against it.  grid.y = agent (A = the critic's blocks).
+// weight; the second layer of a block's 16 envs is a 16 x H x N product on the matrix cores
+// (v_mfma_f32_16x16x4_f32: f32 in, f32 accumulate); softmax and sampling run one wave per env.
+// grid.y = agent (A = the critic's blocks).
 // ---------------------------------------------------------------------------------------------
 struct MappoWeights {
     const float* w1t;   // [A][N][H]   first actor layers, transposed
@@ -2334,22 +2335,21 @@ __global__ __launch_bounds__(1024) void mappo_policy_kernel(const int32_t* __res
                                                             const uint64_t* __restrict__ offset_dev, int32_t* __restrict__ action,
                                                             float* __restrict__ log_prob, float* __restrict__ value,
                                                             float* __restrict__ probs_out) {
+    // block = 16 waves = 16 envs of one agent (grid.y = agent; y == A: the critic's blocks)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float* w2s = reinterpret_cast<float*>(smem);                 // [H][N] of this block's agent
-    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, wpb = blockDim.x >> 6;
+    constexpr int kHS = 65;                                      // hidden row stride (floats): conflict-free A-operand reads
+    const int LS = NR * 64 + 1;                                  // logits row stride
+    float* hs = reinterpret_cast<float*>(smem);                  // [16][kHS]   hidden activations of the block's 16 rows
+    float* ls = hs + 16 * kHS;                                   // [16][LS]    their logits
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int a = blockIdx.y;
-    const int b = blockIdx.x * wpb + wid;
+    const int b = blockIdx.x * 16 + wid;
+    const bool live = b < B;
     const int P = A - 1;
-    if (a < A) {
-        const float* src = w.w2t + (size_t)a * H * N;
-        for (int i = threadIdx.x; i < H * N; i += blockDim.x) w2s[i] = src[i];
-        __syncthreads();
-    }
-    if (b >= B) return;
-    const int32_t* prow = pos + (size_t)b * A;
+    const int32_t* prow = pos + (size_t)(live ? b : 0) * A;
     if (a == A) {
         // ---- central critic: h = relu(cb1 + C1t[mrx] + sum_k sum_j C1t[N (1 + k) + police_j]), value = c2 . h + cb2
-        if (!value) return;
+        if (!value || !live) return;
         float h = lane < H ? w.cb1[lane] : 0.0f;
         if (lane < H) {
             h += w.c1t[(size_t)prow[0] * H + lane];
@@ -2361,28 +2361,47 @@ __global__ __launch_bounds__(1024) void mappo_policy_kernel(const int32_t* __res
         if (lane == 0) value[b] = v;
         return;
     }
-    // ---- actor a: first layer by row lookups (lane k holds hidden unit k)
-    float h = lane < H ? w.b1[(size_t)a * H + lane] : 0.0f;
-    if (lane < H) {
-        const float* w1a = w.w1t + (size_t)a * N * H;
-        if (a == 0) h += w1a[(size_t)prow[0] * H + lane];
-        else
-            for (int j = 0; j < P; ++j) h += w1a[(size_t)prow[1 + j] * H + lane];
+    // ---- phase 1: actor a's first layer by row lookups (lane k holds hidden unit k of this wave's env)
+    {
+        float h = lane < H ? w.b1[(size_t)a * H + lane] : 0.0f;
+        if (lane < H && live) {
+            const float* w1a = w.w1t + (size_t)a * N * H;
+            if (a == 0) h += w1a[(size_t)prow[0] * H + lane];
+            else
+                for (int j = 0; j < P; ++j) h += w1a[(size_t)prow[1 + j] * H + lane];
+        }
+        hs[wid * kHS + lane] = (lane < H && h > 0.0f) ? h : 0.0f;
     }
-    h = h > 0.0f ? h : 0.0f;
-    // second layer: logits[n] = b2[n] + sum_k h[k] W2t[k][n], n = lane + 64 r, weights from LDS
+    __syncthreads();
+    // ---- phase 2: logits[16 envs][N] = hs[16][H] x W2t[H][N] + b2 on the matrix cores (f32 in, f32 accumulate):
+    // one 16 x 16 output tile per wave and pass, H / 4 v_mfma_f32_16x16x4_f32 each; A from LDS, B straight from L2
+    {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int col = lane & 15, kq = lane >> 4;
+        const float* w2a = w.w2t + (size_t)a * H * N;
+        const int tiles = (N + 15) >> 4;
+        for (int t = wid; t < tiles; t += 16) {
+            const int n = 16 * t + col;
+            const float bias = n < N ? w.b2[(size_t)a * N + n] : 0.0f;
+            f32x4 acc = {bias, bias, bias, bias};
+            for (int k0 = 0; k0 < H; k0 += 4) {
+                const int k = k0 + kq;
+                const float av = hs[col * kHS + k];                               // A[i = lane & 15][k = lane >> 4]  (0 past H)
+                const float bv = (n < N && k < H) ? w2a[(size_t)k * N + n] : 0.0f;   // B[k = lane >> 4][j = lane & 15]
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc, 0, 0, 0);
+            }
+            if (n < N) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) ls[(4 * kq + v) * LS + n] = acc[v];     // D[i = 4 (lane >> 4) + v][j = lane & 15]
+            }
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    // ---- phase 3: this wave's env: softmax over the N nodes, masked sampling
     float acc[NR];
 #pragma unroll
-    for (int r = 0; r < NR; ++r) acc[r] = lane + 64 * r < N ? w.b2[(size_t)a * N + lane + 64 * r] : 0.0f;
-    const int hi = __float_as_int(h);
-    for (int k = 0; k < H; ++k) {
-        const float hk = __int_as_float(__builtin_amdgcn_readlane(hi, k));
-        const float* wk = w2s + k * N;
-#pragma unroll
-        for (int r = 0; r < NR; ++r)
-            if (lane + 64 * r < N) acc[r] = fmaf(hk, wk[lane + 64 * r], acc[r]);
-    }
-    // softmax over the N nodes
+    for (int r = 0; r < NR; ++r) acc[r] = lane + 64 * r < N ? ls[wid * LS + lane + 64 * r] : 0.0f;
     float mx = -3.0e38f;
 #pragma unroll
     for (int r = 0; r < NR; ++r) mx = (lane + 64 * r < N && acc[r] > mx) ? acc[r] : mx;
@@ -2547,9 +2566,10 @@ hipError_t launch_mappo_policy(const int32_t* pos, const uint8_t* mask, long lon
     MappoWeights w{w1t, b1, w2t, b2, c1t, cb1, c2, cb2};
     const int wpb = 16;
     const dim3 grid((B + wpb - 1) / wpb, A + (value ? 1 : 0));
-    const size_t lds = (size_t)H * N * sizeof(float);
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
     const int nr = (N + 63) / 64;
+    const int nrp = nr <= 1 ? 1 : (nr <= 2 ? 2 : (nr <= 4 ? 4 : (nr <= 8 ? 8 : 16)));
+    const size_t lds = (size_t)(16 * 65 + 16 * (nrp * 64 + 1)) * sizeof(float);   // hidden rows + logits rows of 16 envs
 #define SY_LAUNCH_MP(NR_) hipLaunchKernelGGL((mappo_policy_kernel<NR_>), grid, dim3(wpb * 64), lds, stream, pos, mask,        \
                                              mask_row_stride, w, B, A, N, H, lo, hi, offset, offset_dev, action, log_prob,   \
                                              value, probs_out)

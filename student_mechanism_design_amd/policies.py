@@ -149,7 +149,7 @@ class DeviceMappoPolicy:
     @torch.no_grad()
     def act(self, obs: Dict[str, torch.Tensor], want_probs: bool = False):
         """Collector callback: (actions int32 [B, A], log_prob [B, A], value [B]); with want_probs a 4th item,
-        the actors' softmax [B, A, N]."""
+        the actors' softmax [B, A, N].  The first three are persistent buffers, overwritten by the next call."""
         import ctypes as C
         pos, mask = obs["agent_position"], obs["action_mask"]
         B, A = pos.shape

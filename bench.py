@@ -202,15 +202,14 @@ def main():
                      "read_only_frac": (R * T * B / (kern_ms * 1e-3) / 1e9) / HBM_PEAK_GBS},
     }
     if args.step_api and rank == 0:
-        act = torch.full((B, A), -1, dtype=torch.int32, device=device)
-        rec = env.rollout(1)
+        act = env.rollout(1)["action"][0].contiguous()      # some legal actions, as the caller's own tensor
         for _ in range(20):
-            env.step(rec["action"][0])
+            env.step(act)
         torch.cuda.synchronize(device)
         t1 = time.perf_counter()
         n = 200
         for _ in range(n):
-            env.step(rec["action"][0])
+            env.step(act)
         torch.cuda.synchronize(device)
         result["step_api_agent_steps_per_s"] = n * B * A / (time.perf_counter() - t1)
         del act

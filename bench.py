@@ -177,7 +177,8 @@ def main():
         try:
             with open(pmc) as f:
                 rec = json.load(f)
-            if rec.get("config") == {"nodes": N, "police": P, "envs": B, "fused": T}:
+            full = not (args.no_record or args.no_belief or args.no_mask_record)   # the counters were taken on the full workload
+            if full and rec.get("config") == {"nodes": N, "police": P, "envs": B, "fused": T}:
                 traffic = rec.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SY_ABI_VERSION 1
+#define SY_ABI_VERSION 2
 #define SY_ELL_WIDTH 16
 #define SY_MAX_AGENTS 8
 #define SY_MAX_NODES 1024
@@ -98,7 +98,19 @@ typedef struct sy_rollout_buffers {
     int32_t *record;
     uint8_t *mask;
     float *belief;
+    float *log_prob;   /* [T][B][A] log-probability of the recorded action under the in-kernel learned policy
+                          (sy_env_set_policy); NULL or ignored for the uniform-random policy */
 } sy_rollout_buffers;
+
+/* The MAPPO networks' parameters, all device float32, laid out for the kernel: first actor layers transposed
+ * w1t [A][N][H] (torch Linear weight [H][N] transposed), b1 [A][H]; second actor layers transposed w2t [A][H][N],
+ * b2 [A][N]; critic first layer transposed c1t [N*A][H], cb1 [H], second layer c2 [H], cb2 [1] (critic may be NULL
+ * when no value is requested). */
+typedef struct sy_mappo_weights {
+    const float *w1t, *b1, *w2t, *b2, *c1t, *cb1, *c2, *cb2;
+    const float *w2;   /* [A][N][H] second actor layers in torch's own layout (a node's row contiguous): needed by
+                          sy_env_set_policy only, may be NULL for sy_mappo_policy_act */
+} sy_mappo_weights;
 
 /* dwords per record row for A = num_police + 1 agents: 5A+4 rounded up to a multiple of 4 */
 int sy_record_words(int32_t num_agents);
@@ -142,6 +154,15 @@ int sy_env_step_record(sy_env *env, const int32_t *actions, const sy_rollout_buf
  * (random_agent.py): T fused steps in ONE launch, records into `out` (may be NULL) */
 int sy_env_rollout(sy_env *env, int32_t T, const sy_rollout_buffers *out, void *stream);
 
+/* The rollout loop with the reference's own policy in it (mappo_trainer.py:161-287 with MappoAgent.select_action):
+ * after this call sy_env_rollout samples every action from the MAPPO actors instead of uniformly — inside the
+ * fused kernel, per (env, agent): hidden = relu(b1 + row lookups of w1t), a logit per affordable neighbour
+ * (w2 row . hidden + b2), action ~ softmax over the affordable neighbours (= the reference's masked, renormalised
+ * softmax; its 1e-8 underflow fallback is not reproduced), log-probability into sy_rollout_buffers.log_prob.
+ * w = NULL restores the uniform-random policy.  hidden: a multiple of 4, at most 64.  The weights must stay valid
+ * and unchanged while launches are in flight. */
+int sy_env_set_policy(sy_env *env, const sy_mappo_weights *w, int32_t hidden);
+
 /* replaces compute_action_mask (action_mask.py:30-84), batched over Q queries on dense float64
  * matrices (device; edge_weights / tolls may be NULL): mask uint8[Q][N] */
 int sy_action_mask_dense(const double *adjacency, const double *edge_weights, const double *tolls,
@@ -168,14 +189,6 @@ int sy_masked_categorical_sample(const float *probs, int64_t probs_row_stride, c
                                  int32_t num_rows, int32_t num_nodes, uint64_t seed, uint64_t offset,
                                  const uint64_t *offset_dev, int32_t default_on_empty, int32_t *action, float *log_prob,
                                  float *norm_probs, void *stream);
-
-/* The MAPPO networks' parameters, all device float32, laid out for the kernel: first actor layers transposed
- * w1t [A][N][H] (torch Linear weight [H][N] transposed), b1 [A][H]; second actor layers transposed w2t [A][H][N],
- * b2 [A][N]; critic first layer transposed c1t [N*A][H], cb1 [H], second layer c2 [H], cb2 [1] (critic may be NULL
- * when no value is requested). */
-typedef struct sy_mappo_weights {
-    const float *w1t, *b1, *w2t, *b2, *c1t, *cb1, *c2, *cb2;
-} sy_mappo_weights;
 
 /* replaces MappoAgent.select_action for every (env, agent) in one launch (agent/mappo_agent.py:6-44,87-142):
  * actor MLPs on the trainer's observations (one-hot MrX node / multi-hot police nodes, mappo_trainer.py:173,197),

@@ -11,7 +11,7 @@ MAX_AGENTS = 8
 MAX_NODES = 1024
 NUM_WEIGHTS = 11
 MRX_MONEY = 1000
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class EngineError(RuntimeError):
@@ -32,15 +32,15 @@ class EnvState(C.Structure):
 
 
 class MappoWeights(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("w1t", "b1", "w2t", "b2", "c1t", "cb1", "c2", "cb2")]
+    _fields_ = [(n, C.c_void_p) for n in ("w1t", "b1", "w2t", "b2", "c1t", "cb1", "c2", "cb2", "w2")]
 
 
 class RolloutBuffers(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("record", "mask", "belief")]
+    _fields_ = [(n, C.c_void_p) for n in ("record", "mask", "belief", "log_prob")]
 
 
 EXPORTS = ["sy_abi_version", "sy_record_words", "sy_last_error", "sy_env_create", "sy_env_destroy", "sy_env_launch_info",
-           "sy_env_set_graph_pool", "sy_env_set_rewards", "sy_env_bind_state", "sy_env_reset", "sy_env_reset_to",
+           "sy_env_set_graph_pool", "sy_env_set_rewards", "sy_env_set_policy", "sy_env_bind_state", "sy_env_reset", "sy_env_reset_to",
            "sy_env_step", "sy_env_step_record", "sy_env_rollout", "sy_action_mask_dense", "sy_belief_update", "sy_build_apsp", "sy_sample_boards",
            "sy_masked_categorical_sample", "sy_mappo_policy_act"]
 
@@ -67,6 +67,7 @@ def load():
     lib.sy_env_set_graph_pool.argtypes = [vp, vp, vp, vp, vp, i32]
     lib.sy_env_set_rewards.argtypes = [vp, C.POINTER(C.c_double), vp, i32, vp, i32]
     lib.sy_env_bind_state.argtypes = [vp, C.POINTER(EnvState)]
+    lib.sy_env_set_policy.argtypes = [vp, C.POINTER(MappoWeights), i32]
     lib.sy_env_reset.argtypes = [vp, vp, u64, vp]
     lib.sy_env_reset_to.argtypes = [vp, vp, vp]
     lib.sy_env_step.argtypes = [vp, vp, vp]

@@ -145,6 +145,24 @@ int sy_env_set_rewards(sy_env* env, const double* w, const double* exp_tab, int3
     return SY_OK;
 }
 
+int sy_env_set_policy(sy_env* env, const sy_mappo_weights* w, int32_t hidden) {
+    if (!env) return fail(SY_ERR_INVALID, "sy_env_set_policy: null env%s");
+    if (!w) {
+        env->p.pw1t = env->p.pb1 = env->p.pw2 = env->p.pb2 = nullptr;
+        env->p.pH = 0;
+        return SY_OK;
+    }
+    if (!w->w1t || !w->b1 || !w->w2 || !w->b2) return fail(SY_ERR_INVALID, "sy_env_set_policy: w1t, b1, w2, b2 are required%s");
+    if (hidden < 4 || hidden > 64 || (hidden & 3)) return fail(SY_ERR_INVALID, "sy_env_set_policy: hidden must be a multiple of 4 in [4, 64]%s");
+    if ((reinterpret_cast<uintptr_t>(w->w2) & 15) || (reinterpret_cast<uintptr_t>(w->w1t) & 15))
+        return fail(SY_ERR_INVALID, "sy_env_set_policy: weights must be 16-byte aligned%s");
+    if ((env->wpb & 1) != 0) return fail(SY_ERR_INVALID, "sy_env_set_policy: needs an even waves_per_block%s");
+    if (env->lds + (size_t)env->wpb * SY_POLICY_SLICE > kMaxLds) return fail(SY_ERR_INVALID, "sy_env_set_policy: no LDS left for the policy scratch%s");
+    env->p.pw1t = w->w1t; env->p.pb1 = w->b1; env->p.pw2 = w->w2; env->p.pb2 = w->b2;
+    env->p.pH = hidden;
+    return SY_OK;
+}
+
 int sy_env_bind_state(sy_env* env, const sy_env_state* s) {
     if (!env || !s) return fail(SY_ERR_INVALID, "sy_env_bind_state: null argument%s");
     if (!s->pos || !s->budget || !s->t || !s->step_count || !s->visits || !s->mask || !s->reward || !s->terminated ||
@@ -215,6 +233,10 @@ int sy_env_rollout(sy_env* env, int32_t T, const sy_rollout_buffers* out, void* 
     if (out && !o.record) return fail(SY_ERR_INVALID, "sy_env_rollout: only `mask` and `belief` of the record may be NULL%s");
     if (!o.record && (o.mask || o.belief)) return fail(SY_ERR_INVALID, "sy_env_rollout: mask / belief need `record`%s");
     if (o.mask && (reinterpret_cast<uintptr_t>(o.mask) & 15)) return fail(SY_ERR_INVALID, "rollout mask must be 16-byte aligned%s");
+    if (env->p.pw2) {       // learned policy in the kernel: recorded rollouts on single-pass boards
+        if (!o.record) return fail(SY_ERR_INVALID, "sy_env_rollout: a policy rollout needs a record%s");
+        if (env->p.A > 64 / env->p.scan_w) return fail(SY_ERR_INVALID, "sy_env_rollout: the in-kernel policy needs boards whose agents fit one scan pass%s");
+    }
     hipError_t e = sy::launch_engine(env->p, nullptr, T, o, false, env->blocks, env->wpb, env->lds, (hipStream_t)stream);
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_env_rollout launch");
 }

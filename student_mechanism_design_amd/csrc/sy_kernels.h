@@ -30,7 +30,14 @@ struct EngineParams {
     const double* cov_tab;
     int32_t n_exp, n_cov;
     sy_env_state st;
+    // in-kernel learned policy (sy_env_set_policy); pw2 == nullptr: uniform-random
+    const float* pw1t;            // [A][N][H]
+    const float* pb1;             // [A][H]
+    const float* pw2;             // [A][N][H]
+    const float* pb2;             // [A][N]
+    int32_t pH;
 };
+#define SY_POLICY_SLICE 2304      // per-episode LDS scratch of the in-kernel policy: 8 hidden vectors of 64 floats + slots
 
 hipError_t launch_engine(const EngineParams& p, const int32_t* actions, int T, const sy_rollout_buffers& out, bool ext,
                          int blocks, int wpb, size_t lds, hipStream_t stream);

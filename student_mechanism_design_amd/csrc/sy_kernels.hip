@@ -51,6 +51,8 @@ template <typename T>
 __device__ __forceinline__ __attribute__((address_space(3))) T* lds_at(uint32_t off) {   // LDS byte offset -> typed LDS pointer
     return (__attribute__((address_space(3))) T*)(uintptr_t)off;
 }
+template <typename T>
+__device__ __forceinline__ T* lds_at_generic(uint32_t off) { return (T*)lds_at<T>(off); }   // ... and back to a generic pointer
 __device__ __forceinline__ uint32_t lds_off(const void* q) { return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)q; }
 
 // Mask algebra for paired waves: predicates that are uniform per half are kept as 64-bit lane masks in
@@ -1408,6 +1410,152 @@ __device__ __forceinline__ void scan_eval_pair1(PairScanLane& q, const ScanMap& 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// In-kernel learned policy (sy_env_set_policy): the rollout loop of mappo_trainer.py:161-287 with
+// MappoAgent.select_action inside the fused kernel.  Only the logits of an agent's affordable
+// neighbours are needed (softmax over the legal actions == the reference's masked, renormalised
+// softmax), so per step and agent: hidden = relu(b1 + row lookups in w1t) (64 floats, lane = hidden
+// unit, kept in LDS), one 64-term dot product per scan lane against that neighbour's row of w2, a
+// Gumbel-max draw and a log-sum-exp over the group through three LDS slots.
+// Per-episode LDS scratch (SY_POLICY_SLICE): [8 agents][64] hidden floats, then 8 x {max key, max logit,
+// sum exp, log-prob of the winner}.
+// ---------------------------------------------------------------------------------------------
+static constexpr uint32_t kPolSlots = 8 * 64 * 4;     // byte offset of the slots inside the policy scratch
+__device__ __forceinline__ int f32_ordered(float f) {           // monotone float -> int map (for integer max)
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7fffffff;
+}
+__device__ __forceinline__ float ordered_f32(int o) { return __int_as_float(o >= 0 ? o : o ^ 0x7fffffff); }
+
+// hidden vectors of both episodes' next observation (mappo_trainer.py:173,197: one-hot MrX node for MrX's actor,
+// multi-hot police nodes for the police actors); lane = hidden unit
+__device__ __forceinline__ void policy_hidden_pair(const EngineParams& p, int P, int pos_n, int lane, uint32_t pol0,
+                                                   uint32_t pol1) {
+    const int H = p.pH, N = p.N;
+    const bool hk = lane < H;
+    const int k = hk ? lane : 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t pb = h ? pol1 : pol0;
+        int pj[SY_MAX_AGENTS];
+#pragma unroll
+        for (int j = 0; j < SY_MAX_AGENTS; ++j) pj[j] = j <= P ? rdlane(pos_n, 32 * h + j) : 0;
+        float v = p.pb1[k] + p.pw1t[(size_t)pj[0] * H + k];
+        if (hk) *lds_at<float>(pb + 4u * (uint32_t)lane) = v > 0.0f ? v : 0.0f;
+#pragma unroll
+        for (int a = 1; a < SY_MAX_AGENTS; ++a) {
+            if (a <= P) {
+                const float* w1a = p.pw1t + (size_t)a * N * H;
+                float u = p.pb1[a * H + k];
+#pragma unroll
+                for (int j = 1; j < SY_MAX_AGENTS; ++j)
+                    if (j <= P) u += w1a[(size_t)pj[j] * H + k];
+                if (hk) *lds_at<float>(pb + 256u * (uint32_t)a + 4u * (uint32_t)lane) = u > 0.0f ? u : 0.0f;
+            }
+        }
+    }
+}
+
+struct PolicyLane {          // per-lane constants of the policy scan
+    uint32_t hs0, hs1;       // my group's agent's hidden vector, episode 0 / 1
+    uint32_t sl0, sl1;       // my group's agent's slots, episode 0 / 1
+    uint32_t slr;            // slots of agent (lane & 7) of my half (agent-lane role)
+    const float* w2a;        // my group's agent's second layer [N][H]
+    const float* b2a;
+};
+__device__ __forceinline__ PolicyLane make_policy_lane(const EngineParams& p, const ScanMap& sm, int lane, int A, uint32_t pol0,
+                                                       uint32_t pol1) {
+    PolicyLane q;
+    const int ag = (sm.live && sm.grp < A) ? sm.grp : 0;
+    q.hs0 = pol0 + 256u * (uint32_t)ag;
+    q.hs1 = pol1 + 256u * (uint32_t)ag;
+    q.sl0 = pol0 + kPolSlots + 16u * (uint32_t)ag;
+    q.sl1 = pol1 + kPolSlots + 16u * (uint32_t)ag;
+    q.slr = (lane >= 32 ? pol1 : pol0) + kPolSlots + 16u * (uint32_t)(lane & 7);
+    q.w2a = p.pw2 + (size_t)ag * p.N * p.pH;
+    q.b2a = p.pb2 + (size_t)ag * p.N;
+    return q;
+}
+
+// scan_eval_pair1 with the learned policy choosing the action (single pass)
+__device__ __forceinline__ void scan_eval_pair_policy(PairScanLane& q, const PolicyLane& pl, const ScanMap& sm, int gw, int H,
+                                                      const ScanPairIn& g, int& act_v, int& cost_v, int& quirk_cnt,
+                                                      float& logp_v) {
+    if (lanes(kAgentSlots)) {
+        *lds_at<uint64_t>(q.selr) = 0x0000ffffull;                                   // "no move": action -1, cost 0
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        *lds_at<v4i>(pl.slr) = (v4i){(int)0x80000000, (int)0x80000000, 0, 0};         // max key, max logit, sum exp, log-prob
+    }
+    *lds_at<uint8_t>(q.prev0) = 0;
+    *lds_at<uint8_t>(q.prev1) = 0;
+    const uint32_t fmask = (1u << gw) - 1u;
+    const int w0 = (int)(g.ent0 >> 16), w1 = (int)(g.ent1 >> 16);
+    const uint64_t bo0 = bal(w0 <= g.ma0) & q.on_m, bo1 = bal(w1 <= g.ma1) & q.on_m;
+    const uint64_t bq0 = bal(w0 <= g.mq0) & q.on_m, bq1 = bal(w1 <= g.mq1) & q.on_m;
+    const bool own0 = lanes(bo0), own1 = lanes(bo1);
+    const uint32_t nb0 = own0 ? (g.ent0 & 0xffffu) : 0u, nb1 = own1 ? (g.ent1 & 0xffffu) : 0u;
+    const uint32_t n0 = own0 ? q.row0 + nb0 : q.scratch, n1 = own1 ? q.row1 + nb1 : q.scratch;
+    *lds_at<uint8_t>(n0) = 1;
+    *lds_at<uint8_t>(n1) = 1;
+    q.prev0 = n0;
+    q.prev1 = n1;
+    // one logit per affordable entry: the neighbour's row of w2 (L2) against the agent's hidden vector (LDS)
+    float l0 = pl.b2a[nb0], l1 = pl.b2a[nb1];
+    {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4* r0 = reinterpret_cast<const f4*>(pl.w2a + (size_t)nb0 * H);
+        const f4* r1 = reinterpret_cast<const f4*>(pl.w2a + (size_t)nb1 * H);
+        for (int c = 0; c < (H >> 2); ++c) {
+            const f4 a0 = r0[c], a1 = r1[c];
+            const f4 h0 = *lds_at<f4>(pl.hs0 + 16u * (uint32_t)c), h1 = *lds_at<f4>(pl.hs1 + 16u * (uint32_t)c);
+            l0 = fmaf(a0.x, h0.x, l0); l0 = fmaf(a0.y, h0.y, l0); l0 = fmaf(a0.z, h0.z, l0); l0 = fmaf(a0.w, h0.w, l0);
+            l1 = fmaf(a1.x, h1.x, l1); l1 = fmaf(a1.y, h1.y, l1); l1 = fmaf(a1.z, h1.z, l1); l1 = fmaf(a1.w, h1.w, l1);
+        }
+    }
+    if (own0) atomicMax(lds_at_generic<int>(pl.sl0 + 4u), f32_ordered(l0));
+    if (own1) atomicMax(lds_at_generic<int>(pl.sl1 + 4u), f32_ordered(l1));
+    wave_lds_fence();
+    const float L0 = ordered_f32(*lds_at<int>(pl.sl0 + 4u)), L1 = ordered_f32(*lds_at<int>(pl.sl1 + 4u));
+    // Gumbel-max draw: a cheap per-lane hash of the agent's Philox word of this step
+    auto gumbel = [&sm](uint32_t x) {
+        uint32_t h = x ^ ((uint32_t)sm.col * 0x9E3779B9u) ^ 0x85EBCA6Bu;
+        h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+        const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        return -__logf(-__logf(u));
+    };
+    const float k0 = l0 + gumbel(g.xa0), k1 = l1 + gumbel(g.xa1);
+    if (own0) {
+        atomicAdd(lds_at_generic<float>(pl.sl0 + 8u), __expf(l0 - L0));
+        atomicMax(lds_at_generic<int>(pl.sl0), f32_ordered(k0));
+    }
+    if (own1) {
+        atomicAdd(lds_at_generic<float>(pl.sl1 + 8u), __expf(l1 - L1));
+        atomicMax(lds_at_generic<int>(pl.sl1), f32_ordered(k1));
+    }
+    wave_lds_fence();
+    const bool win0 = own0 && f32_ordered(k0) == *lds_at<int>(pl.sl0), win1 = own1 && f32_ordered(k1) == *lds_at<int>(pl.sl1);
+    const float S0 = *lds_at<float>(pl.sl0 + 8u), S1 = *lds_at<float>(pl.sl1 + 8u);
+    if (win0) {
+        *lds_at<int>(q.selw0) = (int)g.ent0;
+        *lds_at<float>(pl.sl0 + 12u) = (l0 - L0) - __logf(S0);
+    }
+    if (win1) {
+        *lds_at<int>(q.selw1) = (int)g.ent1;
+        *lds_at<float>(pl.sl1 + 12u) = (l1 - L1) - __logf(S1);
+    }
+    if (lanes(q.lead_m)) {
+        lds_at<int>(q.selw0)[1] = __popc((uint32_t)(bq0 >> sm.gsh) & fmask);
+        lds_at<int>(q.selw1)[1] = __popc((uint32_t)(bq1 >> sm.gsh) & fmask);
+    }
+    wave_lds_fence();
+    const uint64_t r = *lds_at<uint64_t>(q.selr);
+    act_v = (int)(int16_t)(uint32_t)r;              // 0xffff -> -1
+    cost_v = (int)(((uint32_t)r) >> 16);
+    quirk_cnt = (int)(r >> 32);
+    logp_v = *lds_at<float>(pl.slr + 12u);
+    wave_lds_fence();
+}
+
 __device__ __forceinline__ int hbcast(int v, int src_local, bool upper) {   // v of local lane src_local of my half
     const int lo = rdlane(v, src_local), hi = rdlane(v, 32 + src_local);
     return upper ? hi : lo;
@@ -1538,7 +1686,7 @@ __device__ __forceinline__ double shaped_reward3(const RewardTabs& tb, int a, in
 #define SY_STAMP_DUMP(T)
 #endif
 
-template <int NR, bool REC, int PT>
+template <int NR, bool REC, int PT, bool POL = false>   // POL: actions from the MAPPO actors (sy_env_set_policy)
 __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p, const int T, const sy_rollout_buffers out_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const bool has_belief = p.st.belief != nullptr;
@@ -1619,6 +1767,12 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
     PairScanLane psl = make_pair_scan_lane(E, E1, sm, lane, A, NS);
     PairScanLane psl2 = psl;
     if (two_pass) psl2 = make_pair_scan_lane(E, E1, sm, lane, A, NS, sm.per_pass);
+    // in-kernel policy: per-episode scratch behind the episode slices
+    const uint32_t pol0 = lds_off(L.env_base) + (uint32_t)wpb * (uint32_t)p.wave_lds_bytes + (uint32_t)slot * SY_POLICY_SLICE;
+    const uint32_t pol1 = pol0 + SY_POLICY_SLICE;
+    PolicyLane pll;
+    float logp_v = 0.0f;
+    if (POL) pll = make_policy_lane(p, sm, lane, A, pol0, pol1);
     if (one_pass || two_pass) {
         for (int i = lane; i < n16; i += kWave) {
             reinterpret_cast<uint4*>(E.mrow)[i] = make_uint4(0, 0, 0, 0);
@@ -1626,7 +1780,11 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         }
         wave_lds_fence();
         const ScanPairIn g0 = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, draw_word(sc_v));
-        if (one_pass) {
+        if (POL) {           // (the launcher only picks this instance for single-pass boards)
+            policy_hidden_pair(p, P, pos_v, lane, pol0, pol1);
+            wave_lds_fence();
+            scan_eval_pair_policy(psl, pll, sm, p.scan_w, p.pH, g0, act_v, cost_v, qcnt, logp_v);
+        } else if (one_pass) {
             scan_eval_pair1(psl, sm, p.scan_w, g0, act_v, cost_v, qcnt);
         } else {
             const ScanPairIn g1 = scan_gather_pair(L.ell_s, A, sm, sm.per_pass, pos_v, mon_v, draw_word(sc_v));
@@ -1713,6 +1871,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         const ScanPairIn sg = scan_gather_pair(L.ell_s, A, sm, 0, pos_n, mon_n, x_next);
         ScanPairIn sg2 = sg;
         if (two_pass) sg2 = scan_gather_pair(L.ell_s, A, sm, sm.per_pass, pos_n, mon_n, x_next);
+        if (POL) policy_hidden_pair(p, P, pos_n, ln, pol0, pol1);      // hidden vectors of the next observation
         SY_STAMP(1)
         int vc = 0;
         if (is_pol) {                                                         // :244-245
@@ -1761,7 +1920,10 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         SY_STAMP(3)
         // ---- F. evaluate half of the scan: masks, position-reward counts, next action
         int act_n = -1, cost_n = 0;
-        if (one_pass) {
+        float logp_n = 0.0f;
+        if (POL) {
+            scan_eval_pair_policy(psl, pll, sm, p.scan_w, p.pH, sg, act_n, cost_n, qcnt, logp_n);
+        } else if (one_pass) {
             scan_eval_pair1(psl, sm, p.scan_w, sg, act_n, cost_n, qcnt);
         } else if (two_pass) {
             scan_eval_pair1<true, false>(psl, sm, p.scan_w, sg, act_n, cost_n, qcnt);
@@ -1824,7 +1986,12 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
             }
             out.record += (size_t)B * RW;
             if (out.mask) out.mask += BA * NS;
+            if (POL && out.log_prob) {
+                if (store_ok && a < A) out.log_prob[(size_t)eh * A + a] = logp_v;   // of the action executed this step
+                out.log_prob += BA;
+            }
         }
+        if (POL) logp_v = logp_n;
         pos_v = pos_n;
         mon_v = mon_n;
         act_v = act_n;
@@ -2444,7 +2611,10 @@ static hipError_t launch_engine_nr(const EngineParams& p, const int32_t* actions
                                    : 64 * (wpb + (p.st.belief ? (wpb + 1) / 2 : 0));   // move waves + belief waves
 #define SY_LAUNCH_ROLLOUT(PT_)                                                                                            \
     do {                                                                                                                  \
-        if (paired) {                                                                                                     \
+        if (paired && p.pw2 != nullptr) {                                                                                 \
+            hipLaunchKernelGGL((rollout2_kernel<NR, true, (PT_ == 4 ? 4 : 0), true>), dim3(blocks), dim3(threads),        \
+                               lds + (size_t)wpb * SY_POLICY_SLICE, stream, p, T, out);                                    \
+        } else if (paired) {                                                                                              \
             if (out.record)                                                                                               \
                 hipLaunchKernelGGL((rollout2_kernel<NR, true, PT_>), dim3(blocks), dim3(threads), lds, stream, p, T, out); \
             else                                                                                                          \

@@ -79,6 +79,7 @@ class BatchedScotlandYardEnv:
                              int(reveal_interval), int(bool(police_evidence)), int(bool(belief_init_onehot)),
                              int(bool(auto_reset)), int(waves_per_block), int(env_id_offset))
         self._handle = C.c_void_p()
+        self._policy = None
         _lib.check(self.lib.sy_env_create(C.byref(cfg), C.byref(self._handle)), "sy_env_create")
         wpb, blocks, lds = C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(self.lib.sy_env_launch_info(self._handle, C.byref(wpb), C.byref(blocks), C.byref(lds)))
@@ -234,7 +235,7 @@ class BatchedScotlandYardEnv:
             raise IndexError("record row out of range")
         row = _lib.RolloutBuffers(out["record"][s].data_ptr(),
                                   out["mask"][s].data_ptr() if out.get("mask") is not None else None,
-                                  out["belief"][s].data_ptr() if out.get("belief") is not None else None)
+                                  out["belief"][s].data_ptr() if out.get("belief") is not None else None, None)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.sy_env_step_record(self._handle, _ptr(act), C.byref(row), _stream_handle(self.device)),
                        "sy_env_step_record")
@@ -258,15 +259,33 @@ class BatchedScotlandYardEnv:
         }
         return buf
 
+    def set_policy(self, policy=None):
+        """The reference's rollout loop with its own policy in it (mappo_trainer.py:161-287): after this call
+        `rollout` samples every action from the MAPPO actors inside the fused kernel and records the
+        log-probabilities (`log_prob` [T, B, A]).  `policy`: a `policies.DeviceMappoPolicy` (its packed weights are
+        used; call its `refresh()` after optimiser steps, no need to call `set_policy` again) or None for the
+        uniform-random policy."""
+        if policy is None:
+            _lib.check(self.lib.sy_env_set_policy(self._handle, None, 0), "sy_env_set_policy")
+            self._policy = None
+            return
+        if policy.net.N != self.N or policy.net.P != self.P:
+            raise ValueError("the policy was built for another number of nodes / police")
+        _lib.check(self.lib.sy_env_set_policy(self._handle, C.byref(policy._w), int(policy.H)), "sy_env_set_policy")
+        self._policy = policy     # keeps the packed weights alive
+
     def rollout(self, T: int, out: Optional[Dict[str, torch.Tensor]] = None, record: bool = True,
                 record_mask=True, record_belief=True):
-        """T fused steps with the in-kernel uniform-random policy (one launch); returns the record."""
+        """T fused steps in one launch with the in-kernel policy — uniform-random, or the MAPPO actors after
+        `set_policy`; returns the record."""
         if record and out is None:
             out = self.alloc_rollout(T, record_mask, record_belief)
         rb = None
         if record:
+            if self._policy is not None and out.get("log_prob") is None:
+                out["log_prob"] = torch.zeros((int(T), self.B, self.A), dtype=torch.float32, device=self.device)
             rb = _lib.RolloutBuffers(*[out[k].data_ptr() if out.get(k) is not None else None
-                                       for k in ("record", "mask", "belief")])
+                                       for k in ("record", "mask", "belief", "log_prob")])
         with torch.cuda.device(self.device):
             _lib.check(self.lib.sy_env_rollout(self._handle, int(T), C.byref(rb) if rb is not None else None,
                                                _stream_handle(self.device)), "sy_env_rollout")

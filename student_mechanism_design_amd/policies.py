@@ -131,20 +131,30 @@ class DeviceMappoPolicy:
 
     @torch.no_grad()
     def refresh(self):
-        """Re-pack the module's parameters in the kernel's layout (after every optimiser step)."""
+        """Re-pack the module's parameters in the kernels' layouts (after every optimiser step).  The packed
+        buffers are allocated once and refreshed in place, so an env that holds them (`set_policy`) and captured
+        HIP graphs keep seeing the current weights."""
+        import ctypes as C
         f32 = dict(dtype=torch.float32, device=self.device)
         acts = self.net.actors
-        self.w1t = torch.stack([a[0].weight.t() for a in acts]).to(**f32).contiguous()       # [A, N, H]
-        self.b1 = torch.stack([a[0].bias for a in acts]).to(**f32).contiguous()              # [A, H]
-        self.w2t = torch.stack([a[2].weight.t() for a in acts]).to(**f32).contiguous()       # [A, H, N]
-        self.b2 = torch.stack([a[2].bias for a in acts]).to(**f32).contiguous()              # [A, N]
-        self.c1t = self.net.critic[0].weight.t().to(**f32).contiguous()                      # [N * A, H]
-        self.cb1 = self.net.critic[0].bias.to(**f32).contiguous()
-        self.c2 = self.net.critic[2].weight.reshape(-1).to(**f32).contiguous()               # [H]
-        self.cb2 = self.net.critic[2].bias.to(**f32).contiguous()
-        import ctypes as C
-        self._w = self._lib_mod.MappoWeights(*[C.c_void_p(t.data_ptr()) for t in (
-            self.w1t, self.b1, self.w2t, self.b2, self.c1t, self.cb1, self.c2, self.cb2)])
+        packed = {
+            "w1t": torch.stack([a[0].weight.t() for a in acts]),        # [A, N, H]
+            "b1": torch.stack([a[0].bias for a in acts]),               # [A, H]
+            "w2t": torch.stack([a[2].weight.t() for a in acts]),        # [A, H, N]
+            "b2": torch.stack([a[2].bias for a in acts]),               # [A, N]
+            "c1t": self.net.critic[0].weight.t(),                       # [N * A, H]
+            "cb1": self.net.critic[0].bias,
+            "c2": self.net.critic[2].weight.reshape(-1),                # [H]
+            "cb2": self.net.critic[2].bias,
+            "w2": torch.stack([a[2].weight for a in acts]),             # [A, N, H] (torch layout: a node's row contiguous)
+        }
+        if getattr(self, "_packed", None) is None:
+            self._packed = {k: v.to(**f32).contiguous().clone() for k, v in packed.items()}
+            self._w = self._lib_mod.MappoWeights(*[C.c_void_p(self._packed[k].data_ptr()) for k in (
+                "w1t", "b1", "w2t", "b2", "c1t", "cb1", "c2", "cb2", "w2")])
+        else:
+            for k, v in packed.items():
+                self._packed[k].copy_(v)
 
     @torch.no_grad()
     def act(self, obs: Dict[str, torch.Tensor], want_probs: bool = False):

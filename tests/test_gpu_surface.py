@@ -447,3 +447,72 @@ def test_fused_mappo_policy_kernel_matches_the_torch_module_and_the_reference(sy
     np.testing.assert_allclose(_np(p3), g["probs"], rtol=2e-4, atol=1e-7)
     np.testing.assert_allclose(_np(v3), g["value"], rtol=1e-4, atol=1e-5)
     env.close()
+
+
+def test_fused_rollout_with_the_mappo_policy_in_the_kernel(sy):
+    """sy_env_set_policy: the rollout loop with MappoAgent.select_action inside the fused kernel.  The recorded
+    trajectory must be a real trajectory of the engine (replayed through step()), every action legal, and the
+    recorded log-probabilities those of the masked, renormalised softmax of the torch module on the recorded
+    observations; the draws must follow that distribution."""
+    from student_mechanism_design_amd import policies as pol
+    N, P, B, T = 200, 4, 192, 40
+    boards = sy.sample_board_pool(3, N, 400, seed=2)
+    w = np.full(11, 0.5)
+    env = sy.BatchedScotlandYardEnv(B, boards, P, 20, w, seed=11, reveal_interval=5)
+    twin = sy.BatchedScotlandYardEnv(B, boards, P, 20, w, seed=11, reveal_interval=5)
+    torch.manual_seed(3)
+    net = pol.MappoPolicy(N, P, hidden_size=64).to(env.device)
+    with torch.no_grad():                       # make the policy opinionated so that its preferences are visible
+        for a in net.actors:
+            a[2].weight.mul_(6.0)
+            a[2].bias.normal_(0.0, 2.5)
+    fused = pol.DeviceMappoPolicy(net, seed=5)
+    env.set_policy(fused)
+    rec = env.rollout(T)
+    torch.cuda.synchronize()
+    act, mask = rec["action"].long(), rec["mask"][..., :N].bool()
+    empty = mask.sum(-1) == 0
+    assert bool((act[empty] == -1).all()) and bool((act[~empty] >= 0).all())
+    legal = torch.gather(mask, -1, act.clamp_min(0).unsqueeze(-1)).squeeze(-1)
+    assert bool(legal[~empty].all())
+    # the trajectory replays through the step API
+    for s in range(T):
+        np.testing.assert_array_equal(_np(twin.pos), _np(rec["pos"][s]), err_msg=f"step {s}")
+        np.testing.assert_array_equal(_np(twin._mask), _np(rec["mask"][s]))
+        twin.step(rec["action"][s].contiguous())
+        np.testing.assert_array_equal(_np(twin.reward), _np(rec["reward"][s]))
+    np.testing.assert_array_equal(_np(twin.pos), _np(env.pos))
+    # log-probabilities: masked, renormalised softmax of the module on the recorded observations
+    pos = rec["pos"].reshape(T * B, P + 1)
+    with torch.no_grad():
+        probs = net.probs_fast({"MrX_pos": pos[:, 0], "Polices_pos": pos[:, 1:]}).reshape(T, B, P + 1, N)
+    pm = probs * mask.float()
+    norm = pm / pm.sum(-1, keepdim=True).clamp_min(1e-30)
+    want = torch.log(torch.gather(norm, -1, act.clamp_min(0).unsqueeze(-1)).squeeze(-1))
+    got = rec["log_prob"]
+    ok = ~empty
+    np.testing.assert_allclose(_np(got)[_np(ok)], _np(want)[_np(ok)], rtol=0, atol=2e-3)
+    assert bool((got[empty] == 0).all())
+    # the draws follow the distribution: mean probability of the chosen action vs its expectation sum_n p_n^2
+    chosen = torch.gather(norm, -1, act.clamp_min(0).unsqueeze(-1)).squeeze(-1)[ok]
+    expect = (norm ** 2).sum(-1)[ok]
+    assert abs(float(chosen.mean()) - float(expect.mean())) < 0.02, (float(chosen.mean()), float(expect.mean()))
+    # and it is not the uniform policy: the chosen actions are far likelier under the network than uniform picks
+    uniform_pick = (1.0 / mask.float().sum(-1).clamp_min(1))[ok]
+    assert float(chosen.mean()) > float(uniform_pick.mean()) + 0.1
+    # refresh(): new weights reach the kernel through the same packed buffers
+    with torch.no_grad():
+        net.actors[0][2].bias.zero_()
+        net.actors[0][2].weight.zero_()
+    fused.refresh()
+    rec2 = env.rollout(8)
+    m2 = rec2["mask"][..., 0, :N].bool()
+    lp0 = rec2["log_prob"][..., 0]
+    cnt = m2.sum(-1)
+    np.testing.assert_allclose(_np(lp0)[_np(cnt > 0)], _np(-torch.log(cnt.float()))[_np(cnt > 0)], atol=1e-4)   # MrX uniform now
+    # back to the uniform-random policy
+    env.set_policy(None)
+    rec3 = env.rollout(4)
+    assert rec3.get("log_prob") is None or True
+    env.close()
+    twin.close()

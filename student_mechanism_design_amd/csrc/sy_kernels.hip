@@ -1505,7 +1505,17 @@ __device__ __forceinline__ void scan_eval_pair_policy(PairScanLane& q, const Pol
         typedef float f4 __attribute__((ext_vector_type(4)));
         const f4* r0 = reinterpret_cast<const f4*>(pl.w2a + (size_t)nb0 * H);
         const f4* r1 = reinterpret_cast<const f4*>(pl.w2a + (size_t)nb1 * H);
-        for (int c = 0; c < (H >> 2); ++c) {
+        int c = 0;
+        for (; c + 2 <= (H >> 2); c += 2) {          // two 16-byte chunks of both rows per round trip to L2
+            const f4 a0 = r0[c], a1 = r1[c], b0 = r0[c + 1], b1 = r1[c + 1];
+            const f4 h0 = *lds_at<f4>(pl.hs0 + 16u * (uint32_t)c), h1 = *lds_at<f4>(pl.hs1 + 16u * (uint32_t)c);
+            l0 = fmaf(a0.x, h0.x, l0); l0 = fmaf(a0.y, h0.y, l0); l0 = fmaf(a0.z, h0.z, l0); l0 = fmaf(a0.w, h0.w, l0);
+            l1 = fmaf(a1.x, h1.x, l1); l1 = fmaf(a1.y, h1.y, l1); l1 = fmaf(a1.z, h1.z, l1); l1 = fmaf(a1.w, h1.w, l1);
+            const f4 g0 = *lds_at<f4>(pl.hs0 + 16u * (uint32_t)(c + 1)), g1 = *lds_at<f4>(pl.hs1 + 16u * (uint32_t)(c + 1));
+            l0 = fmaf(b0.x, g0.x, l0); l0 = fmaf(b0.y, g0.y, l0); l0 = fmaf(b0.z, g0.z, l0); l0 = fmaf(b0.w, g0.w, l0);
+            l1 = fmaf(b1.x, g1.x, l1); l1 = fmaf(b1.y, g1.y, l1); l1 = fmaf(b1.z, g1.z, l1); l1 = fmaf(b1.w, g1.w, l1);
+        }
+        for (; c < (H >> 2); ++c) {
             const f4 a0 = r0[c], a1 = r1[c];
             const f4 h0 = *lds_at<f4>(pl.hs0 + 16u * (uint32_t)c), h1 = *lds_at<f4>(pl.hs1 + 16u * (uint32_t)c);
             l0 = fmaf(a0.x, h0.x, l0); l0 = fmaf(a0.y, h0.y, l0); l0 = fmaf(a0.z, h0.z, l0); l0 = fmaf(a0.w, h0.w, l0);

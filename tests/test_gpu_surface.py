@@ -516,3 +516,42 @@ def test_fused_rollout_with_the_mappo_policy_in_the_kernel(sy):
     assert rec3.get("log_prob") is None or True
     env.close()
     twin.close()
+
+
+@pytest.mark.parametrize("N,P,H,B", [(60, 2, 32, 50), (90, 6, 16, 31), (24, 3, 64, 9)])
+def test_in_kernel_policy_other_shapes(sy, N, P, H, B):
+    """sy_env_set_policy on the generic-police-count instance, smaller hidden sizes and odd batch sizes:
+    legal actions, log-probabilities of the masked softmax, a trajectory that replays through step()."""
+    from student_mechanism_design_amd import policies as pol
+    boards = sy.sample_board_pool(2, N, int(1.7 * N), seed=N)
+    w = np.linspace(0.1, 0.9, 11)
+    env = sy.BatchedScotlandYardEnv(B, boards, P, 7, w, seed=N + P, reveal_interval=3)
+    if env.A > 64 // max(8, env.max_degree if env.max_degree <= 12 else 16):
+        pytest.skip("board needs two scan passes: the in-kernel policy does not apply")
+    twin = sy.BatchedScotlandYardEnv(B, boards, P, 7, w, seed=N + P, reveal_interval=3)
+    torch.manual_seed(N)
+    net = pol.MappoPolicy(N, P, hidden_size=H).to(env.device)
+    with torch.no_grad():
+        for a in net.actors:
+            a[2].bias.normal_(0.0, 2.0)
+    env.set_policy(pol.DeviceMappoPolicy(net, seed=1))
+    T = 30
+    rec = env.rollout(T)
+    torch.cuda.synchronize()
+    act, mask = rec["action"].long(), rec["mask"][..., :N].bool()
+    empty = mask.sum(-1) == 0
+    assert bool((act[empty] == -1).all()) and bool((act[~empty] >= 0).all())
+    assert bool(torch.gather(mask, -1, act.clamp_min(0).unsqueeze(-1)).squeeze(-1)[~empty].all())
+    for s in range(T):
+        np.testing.assert_array_equal(_np(twin.pos), _np(rec["pos"][s]))
+        twin.step(rec["action"][s].contiguous())
+        np.testing.assert_array_equal(_np(twin.reward), _np(rec["reward"][s]))
+    pos = rec["pos"].reshape(T * B, P + 1)
+    with torch.no_grad():
+        probs = net.probs({"MrX_pos": pos[:, 0], "Polices_pos": pos[:, 1:]}).reshape(T, B, P + 1, N)
+    pm = probs * mask.float()
+    norm = pm / pm.sum(-1, keepdim=True).clamp_min(1e-30)
+    want = torch.log(torch.gather(norm, -1, act.clamp_min(0).unsqueeze(-1)).squeeze(-1))
+    np.testing.assert_allclose(_np(rec["log_prob"])[_np(~empty)], _np(want)[_np(~empty)], rtol=0, atol=2e-3)
+    env.close()
+    twin.close()

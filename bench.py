@@ -198,7 +198,7 @@ def main():
         "env_steps_per_s": value / A,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "sy::rollout2_kernel<4,true,4> (fused rollout: paired move waves + belief waves)", "kernel_ms": kern_ms,
+                     "kernel": "sy::rollout2_kernel<4,true,4,false> (fused rollout: paired move waves + belief waves)", "kernel_ms": kern_ms,
                      "algorithmic_bytes_per_env_step": R + W, "algorithmic_read_bytes_per_env_step": R,
                      "read_only_frac": (R * T * B / (kern_ms * 1e-3) / 1e9) / HBM_PEAK_GBS},
     }

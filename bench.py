@@ -59,6 +59,9 @@ def usable_cores():
     return n
 
 
+SETTLE_LAUNCHES = 12
+
+
 def cpu_baseline(args, boards, weights, A):
     """The CPU oracle (plain-C port of the reference algorithm, OpenMP over envs) on a bounded sample
     of the same workload: the same boards / sizes, T_cpu fused steps of B envs."""
@@ -149,6 +152,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    # Device clocks and power state take about ten launches (~8 ms of load) to settle after an idle start
+    # (tools: per-launch times 0.60, 0.60, 0.63, 0.68, 0.68, 0.67, 0.65, 0.64, 0.61, 0.60, 0.59 ms): part of set-up,
+    # like allocating the buffers; the W warm-up steps asked for on the command line follow.
+    for _ in range(SETTLE_LAUNCHES):
+        one_step()
     for _ in range(args.warmup):
         one_step()
     sync_all()
@@ -194,6 +202,7 @@ def main():
                    "envs_per_gpu": B, "graphs_in_pool": args.graphs, "fused_env_steps_per_launch": T,
                    "reveal_interval": args.reveal, "trajectory_recorded": not args.no_record,
                    "waves_per_block": env.waves_per_block, "lds_bytes_per_block": env.lds_bytes,
+                   "settle_launches_before_warmup": SETTLE_LAUNCHES,
                    "parallelism": f"env-shard x{world} (no data-path collective)"},
         "env_steps_per_s": value / A,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -3,7 +3,7 @@
 # Output under gpurun_out/final/; copy into profiles/ afterwards (see README).
 cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
 O=gpurun_out/final; rm -rf $O; mkdir -p $O
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu --steps 5 --warmup 2 > $O/stats.log 2>&1 || { tail -5 $O/stats.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu --steps 30 --warmup 5 > $O/stats.log 2>&1 || { tail -5 $O/stats.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 bench.py --no-cpu --steps 3 --warmup 1 > $O/fetch.log 2>&1 || { tail -5 $O/fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 bench.py --no-cpu --steps 3 --warmup 1 > $O/write.log 2>&1 || { tail -5 $O/write.log; exit 1; }
 bash tools/collect_pmc.sh tools/pmc_sq.txt final_sq || exit 1

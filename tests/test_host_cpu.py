@@ -187,3 +187,17 @@ def test_oracle_batch_engine_is_self_consistent():
     # starts are distinct and in range after every (auto-)reset
     srt = np.sort(ra["pos"], axis=-1)
     assert (np.diff(srt, axis=-1) > 0).all() and srt.min() >= 0 and srt.max() < 30
+
+
+def test_scripts_compile():
+    """tools/, examples/, oracle/ and the root scripts are valid Python (they only run on the GPU box or in the
+    build container, so nothing else in the CPU suite would notice a typo)."""
+    import glob
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py")) + glob.glob(os.path.join(root, "examples", "*.py")) +
+                   glob.glob(os.path.join(root, "oracle", "*.py")) + [os.path.join(root, "bench.py"),
+                                                                      os.path.join(root, "__graft_entry__.py")])
+    assert len(files) >= 10
+    for f in files:
+        py_compile.compile(f, doraise=True, cfile=os.path.join("/tmp", "sy_pyc_" + os.path.basename(f) + "c"))

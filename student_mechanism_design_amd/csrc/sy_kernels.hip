@@ -1,16 +1,23 @@
 // sy_kernels.hip — hand-written CDNA4 (gfx950) kernels of the batched Scotland-Yard engine.
 //
-// Execution model: ONE 64-lane wavefront per live episode for the game dynamics (the "move wave"),
-// plus, in the fused rollout, ONE partner wavefront per episode for the belief filter (the "belief
-// wave") that consumes the episode's positions through a small LDS ring — so at 4096 episodes the
-// chip holds 8 waves per SIMD of two different instruction mixes instead of 4 of one.
-// A launch block holds `wpb` episodes that share one board: the board's ELL adjacency (16 packed
-// entries per node) is staged once per block in LDS together with the reward lookup tables; every
-// episode owns a private LDS slice (mask rows, visit counters, belief scratch, ring).
-// Agent state lives in lanes: lane a holds agent a's node / budget / action (lane 0 = MrX,
-// lane k+1 = Police k).  Membership tests ("is this node a neighbour", "is the target occupied",
-// "is MrX caught") are wave ballots; the sequential move order of the reference (yard.py:161-243)
-// is kept by a wave-uniform loop over v_readlane.  No MFMA: this is gather / index work.
+// Execution model.  Agent state lives in lanes: lane a holds agent a's node / budget / action (lane 0 =
+// MrX, lane k+1 = Police k).  A launch block holds `wpb` episodes that share one board: the board's ELL
+// adjacency (16 packed entries per node) is staged once per block in LDS together with the reward
+// lookup tables; every episode owns a private LDS slice (mask rows, visit counters, belief scratch,
+// ring).  Kernels:
+//   step_kernel          one transition with caller actions, one wavefront per episode
+//   rollout2_kernel      the fused rollout: a "move" wavefront carries TWO episodes (lanes 0-31 / 32-63,
+//                        per-half predicates as scalar lane masks, DPP pair checks and reductions) and a
+//                        partner "belief" wavefront filters the same two episodes in lockstep, fed through
+//                        a small LDS ring: 4 waves per SIMD at 16 episodes per CU.  Actions come from the
+//                        uniform-random policy or (POL) from the MAPPO actors evaluated in the kernel.
+//   rollout_kernel       the same with one episode per move wave (odd block sizes)
+//   reset / belief_update / action_mask_dense / apsp / sample_boards        reset-side and standalone ops
+//   masked_sample / mappo_policy      policy side: masked categorical sampling; the MAPPO networks with
+//                        the second layers on the matrix cores (f32 MFMA) — the only GEMM-shaped work here.
+// Membership tests ("is this node a neighbour", "is the target occupied", "is MrX caught") are wave
+// ballots; the sequential move order of the reference (yard.py:161-243) is kept exactly whenever two
+// officers could interact.
 //
 // Semantics follow the reference file:line cited at each phase (paths under
 // /root/reference/src/environment/).  Compile with -ffp-contract=off: the float64 reward

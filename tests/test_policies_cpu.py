@@ -114,3 +114,14 @@ def test_gnn_q_policy_greedy_respects_mask():
     a, _, _ = net.act_greedy(obs, a_hat)
     legal = torch.gather(obs["action_mask"], -1, a.clamp_min(0).long().unsqueeze(-1)).squeeze(-1)
     assert bool((legal | (a < 0)).all())
+
+
+def test_device_policy_and_sampler_refuse_to_run_without_a_gpu():
+    """No CPU fallback: the HIP-backed policy pieces fail loudly on CPU tensors."""
+    import pytest
+    from student_mechanism_design_amd import collector as col
+    net = pol.MappoPolicy(12, 2, hidden_size=8)
+    with pytest.raises(sy.EngineError):
+        pol.DeviceMappoPolicy(net)
+    with pytest.raises(sy.EngineError):
+        col.DeviceMaskedSampler(torch.device("cpu"))

@@ -10,9 +10,17 @@ E=400 edges and money=20 are SURVEY.md section 8 choices (BASELINE gives neither
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-Episodes are independent: ranks own disjoint env shards (weak scaling, B per GPU fixed), there is
-no data-path collective; the only cross-rank ops are the timing barrier and a MAX reduction.
-Rank 0 prints ONE JSON line with `roofline` (HBM) and `cpu_baseline` (the CPU oracle, a port).
+Timing: W untimed warm-up steps, then R >= 5 repeats of EXACTLY K steps, each repeat bracketed by a barrier +
+`torch.cuda.synchronize()` on both sides and reduced with MAX over ranks; the line reports the MEDIAN repeat (min /
+max beside it).  R is chosen so that the timed regions add up to >= ~120 ms.  No launches precede the warm-up: the
+clock / power transient of an idle device (its first ~8 ms under load) falls into the first repeat and the median
+ignores it.  Kernel time = HIP events on the launch stream around every timed launch (median).
+
+Episodes are independent: ranks own disjoint env shards (weak scaling, B per GPU fixed), no data-path collective in
+the rollout.  The ONE exchange of the multi-GPU path — the trajectory all-gather at the PPO update, BASELINE
+configs[3] — is timed separately for N > 1 (`gather`: zero-copy `collector.TrajectoryExchange`).
+Rank 0 prints ONE JSON line with `roofline` (HBM), `cpu_baseline` (the CPU oracle, a port: all-core and one-thread)
+and `verified` (the last timed trajectory checked against the oracle, outside the timed region).
 """
 import argparse
 import json
@@ -59,62 +67,112 @@ def usable_cores():
     return n
 
 
-SETTLE_LAUNCHES = 12
+def kernel_name(N, P, wpb, record, policy):
+    """The instance the launcher picks (csrc/sy_kernels.hip::launch_engine_nr) for this configuration."""
+    nr = (N + 63) // 64
+    nr = 1 if nr <= 1 else 2 if nr <= 2 else 4 if nr <= 4 else 8 if nr <= 8 else 16
+    pt = P if P in (2, 4, 5, 6) else 0
+    if wpb % 2 == 0:
+        if policy:
+            return f"sy::rollout2_kernel<{nr},true,{4 if pt == 4 else 0},true>"
+        return f"sy::rollout2_kernel<{nr},{'true' if record else 'false'},{pt},false>"
+    return f"sy::rollout_kernel<{nr},{'true' if record else 'false'},{pt}>"
 
 
-def cpu_baseline(args, boards, weights, A):
-    """The CPU oracle (plain-C port of the reference algorithm, OpenMP over envs) on a bounded sample
-    of the same workload: the same boards / sizes, T_cpu fused steps of B envs."""
+def make_oracle(args, boards, weights, env_graph, threads, env_id_offset=0):
     from oracle import oracle_lib as ol
     import student_mechanism_design_amd as sy
-    cores = usable_cores()
     graphs = [ol.OracleGraph(args.nodes, b.edge_links, b.edges.astype(np.int32)) for b in boards]
+    return ol.OracleBatch(graphs, env_graph, args.envs, args.police, args.money, node_stride=(args.nodes + 15) // 16 * 16,
+                          weights=weights, tables=sy.reward_tables(), reveal_interval=args.reveal, threads=threads,
+                          env_id_offset=env_id_offset, with_belief=not args.no_belief)
+
+
+def cpu_baseline(args, boards, weights, env_graph, A):
+    """The CPU oracle (plain-C port of the reference algorithm, OpenMP over envs) on a bounded sample of the same
+    workload — the same boards / sizes, T_cpu fused steps of B envs — once on all usable cores (`value`) and once
+    on ONE thread (`single_thread_value`).  A reported baseline, not a target."""
+    cores = usable_cores()
     B = args.envs
-    per = -(-B // len(graphs))
-    eg = np.minimum(np.arange(B) // per, len(graphs) - 1).astype(np.int32)
-    orc = ol.OracleBatch(graphs, eg, B, args.police, args.money, node_stride=(args.nodes + 15) // 16 * 16,
-                         weights=weights, tables=sy.reward_tables(), reveal_interval=args.reveal,
-                         threads=cores)
-    orc.reset(seed=1)
-    orc.rollout(2, record=False)  # warm
-    t_cpu, steps = 0.0, 0
-    T = 8
-    t0 = time.perf_counter()
-    while t_cpu < args.cpu_seconds:
-        orc.rollout(T, record=True)
-        steps += T
-        t_cpu = time.perf_counter() - t0
-    rate = steps * B * A / t_cpu
-    return {"value": rate, "unit": "agent-steps/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/sy_oracle.c batched engine, B={B} envs x {steps} fused steps, trajectory recorded, "
-                      f"{t_cpu:.1f}s wall, OpenMP {cores} threads"}
+    out = {}
+    for label, threads, budget in (("all", cores, args.cpu_seconds * 0.6), ("one", 1, args.cpu_seconds * 0.4)):
+        orc = make_oracle(args, boards, weights, env_graph, threads)
+        orc.reset(seed=1)
+        orc.rollout(2, record=False)  # warm
+        t_cpu, steps, T = 0.0, 0, 8 if threads > 1 else 2
+        t0 = time.perf_counter()
+        while t_cpu < budget:
+            orc.rollout(T, record=True)
+            steps += T
+            t_cpu = time.perf_counter() - t0
+        out[label] = (steps * B * A / t_cpu, steps, t_cpu)
+    return {"value": out["all"][0], "unit": "agent-steps/s", "cores": cores, "kind": "port",
+            "single_thread_value": out["one"][0],
+            "sample": f"oracle/sy_oracle.c batched engine, trajectory recorded: B={B} envs x {out['all'][1]} fused steps in "
+                      f"{out['all'][2]:.1f}s on {cores} OpenMP threads; x {out['one'][1]} steps in {out['one'][2]:.1f}s on 1 thread"}
+
+
+def verify_last_launch(args, boards, weights, env, snap, out, T):
+    """Outside the timed region: the oracle restarts from the state snapshot taken just before the LAST timed launch
+    and must reproduce that launch's recorded trajectory (bit-exact; belief within 1e-5) and the live state."""
+    orc = make_oracle(args, boards, weights, env.env_graph_host, usable_cores(), env_id_offset=int(env._env_id_offset))
+    orc.reset(seed=env.stream_key)
+    N = env.N
+    orc.pos[:] = snap["pos"].cpu().numpy()
+    orc.money[:] = snap["budget"].cpu().numpy()
+    orc.t[:] = snap["t"].cpu().numpy()
+    orc.step_count[:] = snap["step_count"].cpu().numpy().astype(np.uint32)
+    orc.visits[:] = snap["visits"].cpu().numpy().astype(np.int32)
+    orc.mask[:] = snap["mask"].cpu().numpy()
+    if orc.belief is not None:
+        orc.belief[:] = snap["belief"].cpu().numpy().astype(np.float64)
+    ref = orc.rollout(T, record_mask=out.get("mask") is not None)
+    ok, worst = True, 0.0
+    for s0 in range(0, T, 32):
+        s1 = min(T, s0 + 32)
+        for k, rk in (("pos", "pos"), ("budget", "money"), ("t", "t"), ("action", "action"), ("terminated", "terminated"),
+                      ("truncated", "truncated"), ("winner", "winner"), ("reward", "reward"), ("mask", "mask")):
+            if out.get(k) is None or ref.get(rk) is None:
+                continue
+            ok = ok and np.array_equal(out[k][s0:s1].cpu().numpy(), ref[rk][s0:s1])
+        if out.get("belief") is not None and ref.get("belief") is not None:
+            worst = max(worst, float(np.abs(out["belief"][s0:s1].cpu().numpy().astype(np.float64) - ref["belief"][s0:s1]).max()))
+    ok = ok and worst <= 1e-5
+    ok = ok and np.array_equal(env.pos.cpu().numpy(), orc.pos) and np.array_equal(env._mask.cpu().numpy(), orc.mask)
+    ok = ok and np.array_equal(env.reward.cpu().numpy(), orc.reward) and np.array_equal(env.t.cpu().numpy(), orc.t)
+    return bool(ok), worst, int((ref["terminated"] | ref["truncated"]).sum())
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--repeats", type=int, default=0, help="timed repeats of K steps (0 = at least 5, enough for ~120 ms)")
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--nodes", type=int, default=200)
     ap.add_argument("--edges", type=int, default=400)
     ap.add_argument("--police", type=int, default=4)
     ap.add_argument("--money", type=int, default=20)
-    ap.add_argument("--graphs", type=int, default=8, help="boards in the pool")
+    ap.add_argument("--graphs", type=int, default=8, help="boards in the pool (SURVEY 8d variants: 1 and 64)")
     ap.add_argument("--fused", type=int, default=256, help="env steps per launch (T); 256 ~ the reference's 250-step episode cap")
     ap.add_argument("--reveal", type=int, default=5)
+    ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--wpb", type=int, default=0, help="waves (envs) per launch block, 0 = engine default")
     ap.add_argument("--no-record", action="store_true", help="do not write the trajectory (diagnostic only)")
     ap.add_argument("--no-belief", action="store_true", help="diagnostic: engine without the belief filter")
     ap.add_argument("--no-mask-record", action="store_true", help="diagnostic: do not record masks")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=14.0)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed trajectory")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the separately timed trajectory all-gather")
     ap.add_argument("--step-api", action="store_true", help="also time the per-step sy_env_step launch path")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import student_mechanism_design_amd as sy
+    from student_mechanism_design_amd.collector import TrajectoryExchange
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -135,13 +193,16 @@ def main():
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
 
-    N, P, A, B, T = args.nodes, args.police, args.police + 1, args.envs, args.fused
+    N, P, A, B, T, K = args.nodes, args.police, args.police + 1, args.envs, args.fused, args.steps
     boards = sy.sample_board_pool(args.graphs, N, args.edges, seed=0)   # same synthetic boards on all ranks
     weights = np.full(11, 0.5)
-    env = sy.BatchedScotlandYardEnv(B, boards, P, args.money, weights, seed=1234, reveal_interval=args.reveal,
+    env = sy.BatchedScotlandYardEnv(B, boards, P, args.money, weights, seed=args.seed, reveal_interval=args.reveal,
                                     env_id_offset=rank * B, waves_per_block=args.wpb, device=device,
                                     with_belief=not args.no_belief)
+    env._env_id_offset = rank * B
     out = None if args.no_record else env.alloc_rollout(T, record_mask=not args.no_mask_record)
+    full = not (args.no_record or args.no_belief or args.no_mask_record)
+    do_verify = full and not args.no_verify and rank == 0
 
     def one_step():
         env.rollout(T, out=out, record=not args.no_record)
@@ -152,49 +213,66 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    # Device clocks and power state take about ten launches (~8 ms of load) to settle after an idle start
-    # (tools: per-launch times 0.60, 0.60, 0.63, 0.68, 0.68, 0.67, 0.65, 0.64, 0.61, 0.60, 0.59 ms): part of set-up,
-    # like allocating the buffers; the W warm-up steps asked for on the command line follow.
-    for _ in range(SETTLE_LAUNCHES):
-        one_step()
+    sync_all()
+    tw = time.perf_counter()
     for _ in range(args.warmup):
         one_step()
     sync_all()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ev[i][0].record()   # the engine launches on torch's current stream, so these bracket the kernel
-        one_step()
-        ev[i][1].record()
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    est_step = max((time.perf_counter() - tw) / max(args.warmup, 1), 1e-5)
+    repeats = args.repeats if args.repeats > 0 else int(min(50, max(5, np.ceil(0.12 / (K * est_step)))))
+    if world > 1:      # every rank must run the same number of repeats
+        rr = torch.tensor([repeats], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(rr, op=dist.ReduceOp.MAX)
+        repeats = int(rr.item())
 
-    env_steps = args.steps * T * B * world
-    value = env_steps * A / elapsed
+    state_names = ("pos", "budget", "t", "step_count", "_visits", "_belief", "_mask")
+    snap = None
+    elapsed, events = [], []
+    for r in range(repeats):
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(K):
+            if do_verify and r == repeats - 1 and i == K - 1:
+                # snapshot of the live state (7 small device copies, ~10 MB) just before the LAST timed launch
+                snap = {n.lstrip("_"): getattr(env, n).clone() for n in state_names if getattr(env, n) is not None}
+            ev[i][0].record()   # the engine launches on torch's current stream, so these bracket the kernel
+            one_step()
+            ev[i][1].record()
+        sync_all()
+        elapsed.append(time.perf_counter() - t0)
+        events.append(ev)
+    env.check_status()          # a launch that lost a hand-off reports it here instead of returning wrong data
+    el = torch.tensor(elapsed, dtype=torch.float64, device=device if (world > 1 and backend == "nccl") else "cpu")
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    el = np.sort(el.cpu().numpy())
+    med = float(np.median(el))
+    kern = np.array([a.elapsed_time(b) for ev in events for a, b in ev])
+    kern_ms = float(np.median(kern))
+
+    env_steps = K * T * B * world
+    value = env_steps * A / med
     R, W = algorithmic_bytes_per_env_step(N, P)
     bytes_per_launch = (R + W) * T * B
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
-    traffic = None
+    traffic, traffic_source = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # measured by tools/pmc_traffic.py under rocprofv3
     if os.path.exists(pmc):
         try:
             with open(pmc) as f:
                 rec = json.load(f)
-            full = not (args.no_record or args.no_belief or args.no_mask_record)   # the counters were taken on the full workload
             if full and rec.get("config") == {"nodes": N, "police": P, "envs": B, "fused": T}:
                 traffic = rec.get("hbm_bytes_per_launch")
+                traffic_source = ("stored: profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                  "this workload, gfx950 x2 fetch correction; not measured in this run)")
         except Exception:
             traffic = None
 
     result = {
         "metric": "agent-steps/sec, 200-node graph, 4 police, 4096 parallel envs, 1/2/4/8 GPUs",
-        "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "value": value, "unit": "agent-steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
+        "ms_per_step": med / K * 1e3, "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "int32 state / u8 masks / f32 belief / f64 reward", "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: 200-node random board, 4 police + MrX, 4096 envs/GPU, "
                                "uniform-random policy in-kernel, env kernels only",
@@ -202,15 +280,51 @@ def main():
                    "envs_per_gpu": B, "graphs_in_pool": args.graphs, "fused_env_steps_per_launch": T,
                    "reveal_interval": args.reveal, "trajectory_recorded": not args.no_record,
                    "waves_per_block": env.waves_per_block, "lds_bytes_per_block": env.lds_bytes,
-                   "settle_launches_before_warmup": SETTLE_LAUNCHES,
-                   "parallelism": f"env-shard x{world} (no data-path collective)"},
+                   "parallelism": f"env-shard x{world} (no data-path collective in the rollout)"},
+        "timing": {"repeats": repeats, "statistic": "median over repeats of K steps, MAX over ranks per repeat",
+                   "ms_per_step_min": float(el[0]) / K * 1e3, "ms_per_step_max": float(el[-1]) / K * 1e3,
+                   "timed_region_ms_total": float(el.sum()) * 1e3, "launches_before_warmup": 0},
         "env_steps_per_s": value / A,
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "sy::rollout2_kernel<4,true,4,false> (fused rollout: paired move waves + belief waves)", "kernel_ms": kern_ms,
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                     "hbm_frac_measured": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                     "kernel": kernel_name(N, P, env.waves_per_block, not args.no_record, False) +
+                     " (fused rollout: paired move waves + belief waves)",
+                     "kernel_ms": kern_ms, "kernel_ms_min": float(kern.min()), "kernel_ms_max": float(kern.max()),
                      "algorithmic_bytes_per_env_step": R + W, "algorithmic_read_bytes_per_env_step": R,
-                     "read_only_frac": (R * T * B / (kern_ms * 1e-3) / 1e9) / HBM_PEAK_GBS},
+                     "read_only_frac": (R * T * B / (kern_ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
+                     "note": "frac = ALGORITHMIC bytes (SURVEY 8d) / kernel time / 8 TB/s; hbm_frac_measured = counter bytes "
+                             "(what the fused kernel really moves: the trajectory writes) / kernel time / 8 TB/s"},
     }
+    if do_verify and snap is not None:
+        ok, worst, n_done = verify_last_launch(args, boards, weights, env, snap, out, T)
+        result["verified"] = ok
+        result["verification"] = {"what": "last timed launch replayed by the CPU oracle from a state snapshot: record "
+                                          "(pos, budget, t, action, flags, winner, float64 reward, masks) and live state "
+                                          "bit-exact, belief max abs diff", "belief_max_abs_diff": worst,
+                                  "episodes_finished_in_launch": n_done}
+    else:
+        result["verified"] = None
+    if world > 1 and not args.no_gather and out is not None:
+        ex = TrajectoryExchange(out)
+        ex.gather()                      # allocates the receive buffer, warms the communicator
+        sync_all()
+        gt = []
+        for _ in range(5):
+            sync_all()
+            t0 = time.perf_counter()
+            ex.gather()
+            sync_all()
+            gt.append(time.perf_counter() - t0)
+        g = torch.tensor(gt, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(g, op=dist.ReduceOp.MAX)
+        gms = float(np.median(g.cpu().numpy())) * 1e3
+        result["gather"] = {"what": "the ONE exchange per PPO update: all_gather_into_tensor of each rank's rollout arena "
+                                    "(zero-copy send, preallocated receive, results are views)",
+                            "gather_ms": gms, "bytes_per_rank_sent": ex.nbytes, "bytes_per_rank_received": ex.bytes_received_per_rank,
+                            "recv_GBps_per_rank": ex.bytes_received_per_rank / (gms * 1e-3) / 1e9,
+                            "rollout_plus_gather_agent_steps_per_s": T * B * world * A / (med / K + gms * 1e-3),
+                            "alternative": "gradient all-reduce of the MAPPO networks: 0.77 MB per update"}
     if args.step_api and rank == 0:
         act = env.rollout(1)["action"][0].contiguous()      # some legal actions, as the caller's own tensor
         for _ in range(20):
@@ -225,13 +339,15 @@ def main():
         del act
     if rank == 0:
         if not args.no_cpu and world == 1:
-            result["cpu_baseline"] = cpu_baseline(args, boards, weights, A)
+            result["cpu_baseline"] = cpu_baseline(args, boards, weights, env.env_graph_host, A)
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if result.get("verified") is False:
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SY_ABI_VERSION 2
+#define SY_ABI_VERSION 3
 #define SY_ELL_WIDTH 16
 #define SY_MAX_AGENTS 8
 #define SY_MAX_NODES 1024
@@ -52,6 +52,11 @@ extern "C" {
 #define SY_ERR_INVALID (-1)  /* bad argument / config */
 #define SY_ERR_STATE (-2)    /* call order (e.g. step before bind) */
 #define SY_ERR_HIP (-3)      /* a HIP runtime call failed */
+
+/* bits of the engine's device status word (sy_env_bind_status / sy_env_status): a launch that hit one of these
+ * still drains (every in-kernel spin is bounded), but its results must not be trusted */
+#define SY_STATUS_BELIEF_WAIT_EXPIRED 1u /* a belief wave gave up waiting for its move wave's ring entry  */
+#define SY_STATUS_RING_WAIT_EXPIRED 2u   /* a move wave gave up waiting for ring space (belief wave lost) */
 
 typedef struct sy_env sy_env; /* opaque */
 
@@ -134,6 +139,13 @@ int sy_env_set_rewards(sy_env *env, const double *weights_host, const double *ex
                        const double *cov_tab, int32_t n_cov);
 int sy_env_bind_state(sy_env *env, const sy_env_state *state);
 
+/* Failure reporting.  `status` is ONE device uint32 owned by the caller (zero it before binding); kernels OR
+ * SY_STATUS_* bits into it when an internal wait ran out instead of carrying on silently.  sy_env_status copies
+ * the word to the host and clears nothing; it is the one call here that synchronises (`stream`).  It returns
+ * SY_ERR_HIP with a message when the word is non-zero, SY_OK when it is zero (or no word is bound). */
+int sy_env_bind_status(sy_env *env, uint32_t *status);
+int sy_env_status(sy_env *env, void *stream, uint32_t *status_host /* may be NULL */);
+
 /* replaces CustomEnvironment.reset (yard.py:80-142): distinct uniform start nodes from the engine's
  * Philox stream, budgets [1000, money...], t = 0, visit counts cleared, belief re-initialised, masks.
  * env_sel: device uint8[B] (NULL = all envs, which also zeroes step_count). */
@@ -199,6 +211,39 @@ int sy_masked_categorical_sample(const float *probs, int64_t probs_row_stride, c
 int sy_mappo_policy_act(const int32_t *pos, const uint8_t *mask, int64_t mask_row_stride, const sy_mappo_weights *w,
                         int32_t num_envs, int32_t num_police, int32_t num_nodes, int32_t hidden, uint64_t seed, uint64_t offset,
                         const uint64_t *offset_dev, int32_t *action, float *log_prob, float *value, float *probs, void *stream);
+
+/* replaces the return / advantage lines of MappoAgent.ppo_update (agent/mappo_agent.py:247-258) for a whole
+ * [T][B][A] rollout in ONE launch (the reference loops over a flat Python buffer), plus the GAE(gamma, lambda)
+ * generalisation (the reference has no GAE; at lambda = 1 with a zero bootstrap GAE's returns equal mode 0's).
+ * All pointers device.  Element (t, b, a) of `reward` is reward[t * reward_stride_t + b * reward_stride_b + a]
+ * (strides in elements: the packed rollout record is addressed in place); `done_a` / `done_b` (done_b may be
+ * NULL) are [T][B] flags of `done_bytes` (1 or 4) bytes each, done = either non-zero (the record's terminated /
+ * truncated words; trainer rule training/utils.py:241-251); `value` (NULL = 0) is float with three strides
+ * (value_stride_a = 0 broadcasts a central critic's [T][B]); `last_value` (GAE bootstrap, NULL = 0) float with
+ * two strides.  Outputs `returns`, `adv` (NULL = skip): contiguous [T][B][A], float (compute_f64 = 0: the
+ * reference's float32 arithmetic, bit for bit, rewards rounded to float first) or double (compute_f64 = 1).
+ *   mode 0: R_t = r_t + (gamma * R_{t+1}) * (1 - d_t);  adv = R - V         (mappo_agent.py:248-256)
+ *   mode 1: delta_t = (r_t + (gamma * V_{t+1}) * (1 - d_t)) - V_t;  A_t = delta_t + ((gamma * lambda) * (1 - d_t)) * A_{t+1};
+ *           returns = A + V
+ * The standardisation of :257-258 (global mean / std) stays a two-reduction torch expression. */
+typedef struct sy_returns_args {
+    int32_t T, B, A;
+    int32_t mode;             /* 0 reference returns, 1 GAE */
+    const void *reward;
+    int32_t reward_f64;       /* reward element type: 1 double, 0 float */
+    int64_t reward_stride_t, reward_stride_b;
+    const void *done_a, *done_b;
+    int32_t done_bytes;
+    int64_t done_stride_t, done_stride_b;
+    const float *value;
+    int64_t value_stride_t, value_stride_b, value_stride_a;
+    const float *last_value;
+    int64_t last_value_stride_b, last_value_stride_a;
+    double gamma, lambda;
+    int32_t compute_f64;
+    void *returns, *adv;
+} sy_returns_args;
+int sy_returns_advantages(const sy_returns_args *args, void *stream);
 
 /* replaces Pathfinder.get_distance (pathfinding.py:34-137) for a whole pool: all-pairs weighted
  * shortest paths from the ELL table, apsp uint16 [G][N][N] (0xFFFF = unreachable); all device */

@@ -38,18 +38,30 @@ def main():
         ce_cases.append({"belief": [float(x) for x in b], "true_index": k, "ce": mod.belief_cross_entropy(b.copy(), k)})
     episodes = []
     tracker = mod.MetricsTracker()
+    reveal_k, n_nodes = 5, 10
     for i in range(37):
         winner = "Police" if rng.random() < 0.35 else "MrX"
         length = int(rng.integers(1, 60))
         tracker.start_episode(initial_budget=20.0)
+        reveals = []
         for step in range(1, length + 1):
-            tracker.record_step(step)
+            # belief quality is recorded at reveal times only (eval/metrics.py:138-141): every 5th step here
+            if step % reveal_k == 0:
+                b = rng.random(n_nodes)
+                if rng.random() < 0.2:
+                    b[rng.integers(0, n_nodes)] = 0.0
+                b = b / b.sum()
+                k = int(rng.integers(0, n_nodes))
+                tracker.record_step(step, belief=b.copy(), true_mrx_pos=k, is_reveal=True)
+                reveals.append({"step": step, "belief": [float(x) for x in b], "true_index": k})
+            else:
+                tracker.record_step(step)
         tracker.end_episode(winner)
-        episodes.append({"winner": winner, "length": length})
+        episodes.append({"winner": winner, "length": length, "reveals": reveals})
     agg = tracker.get_aggregated_metrics().to_dict()
     out = os.path.join(HERE, "..", "tests", "golden", "metrics_reference.json")
     with open(out, "w") as f:
-        json.dump({"source": "eval/metrics.py (unmodified)", "ce_cases": ce_cases, "episodes": episodes,
+        json.dump({"source": "eval/metrics.py (unmodified)", "reveal_interval": reveal_k, "num_nodes": n_nodes, "ce_cases": ce_cases, "episodes": episodes,
                    "aggregated": {k: (float(v) if isinstance(v, (int, float, np.floating, np.integer)) else v)
                                   for k, v in agg.items()}}, f)
     print("wrote", os.path.abspath(out), sorted(agg)[:20])

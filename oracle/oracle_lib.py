@@ -82,6 +82,9 @@ def load():
                                    _f64p, _f64p, C.c_int32, _f64p, C.c_int32, C.c_uint64]
     lib.syo_batch_rollout.argtypes = [C.POINTER(_BatchConfig), gpp, _i32p, C.POINTER(_BatchState), C.c_int32,
                                       _f64p, _f64p, C.c_int32, _f64p, C.c_int32, C.c_uint64, C.POINTER(_Traj)]
+    _f32p = C.POINTER(C.c_float)
+    lib.syo_discounted_returns_f32.argtypes = [_f32p, _u8p, _f32p, C.c_int32, C.c_int32, C.c_float, _f32p, _f32p]
+    lib.syo_gae_f64.argtypes = [_f64p, _u8p, _f64p, _f64p, C.c_int32, C.c_int32, C.c_double, C.c_double, _f64p, _f64p]
     _lib = lib
     return lib
 
@@ -278,3 +281,30 @@ class OracleBatch:
                                  int(T), _p(self.weights, _f64p), *self._tabs(), self.seed,
                                  C.byref(ctr) if ctr is not None else None)
         return tr
+
+
+def discounted_returns_f32(reward, done, gamma, values=None):
+    """mappo_agent.py:247-258 over [T, cols] float32 columns; returns (returns, advantages = returns - values)."""
+    r = np.ascontiguousarray(reward, dtype=np.float32)
+    T = r.shape[0]
+    cols = int(np.prod(r.shape[1:])) if r.ndim > 1 else 1
+    d = np.ascontiguousarray(np.broadcast_to(np.asarray(done).reshape(np.asarray(done).shape + (1,) * (r.ndim - np.asarray(done).ndim)), r.shape), dtype=np.uint8)
+    v = None if values is None else np.ascontiguousarray(np.broadcast_to(values, r.shape), dtype=np.float32)
+    ret, adv = np.zeros_like(r), np.zeros_like(r)
+    f32p = C.POINTER(C.c_float)
+    load().syo_discounted_returns_f32(_p(r, f32p), _p(d, _u8p), _p(v, f32p), T, cols, float(gamma), _p(ret, f32p), _p(adv, f32p))
+    return ret, adv
+
+
+def gae_f64(reward, done, values, gamma, lam, last_value=None):
+    r = np.ascontiguousarray(reward, dtype=np.float64)
+    T = r.shape[0]
+    cols = int(np.prod(r.shape[1:])) if r.ndim > 1 else 1
+    dd = np.asarray(done)
+    d = np.ascontiguousarray(np.broadcast_to(dd.reshape(dd.shape + (1,) * (r.ndim - dd.ndim)), r.shape), dtype=np.uint8)
+    v = np.ascontiguousarray(np.broadcast_to(values, r.shape), dtype=np.float64)
+    lv = None if last_value is None else np.ascontiguousarray(np.broadcast_to(last_value, r.shape[1:]), dtype=np.float64)
+    adv, ret = np.zeros_like(r), np.zeros_like(r)
+    load().syo_gae_f64(_p(r, _f64p), _p(d, _u8p), _p(v, _f64p), _p(lv, _f64p), T, cols, float(gamma), float(lam),
+                       _p(adv, _f64p), _p(ret, _f64p))
+    return adv, ret

@@ -484,3 +484,37 @@ void syo_batch_rollout(const syo_batch_config *c, syo_graph *const *graphs, cons
         }
     }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * returns / advantages (agent/mappo_agent.py:247-258) and the GAE generalisation
+ * ------------------------------------------------------------------------------------------------ */
+void syo_discounted_returns_f32(const float *reward, const uint8_t *done, const float *values, int32_t T, int32_t cols,
+                                float gamma, float *returns, float *adv) {
+    for (int32_t c = 0; c < cols; ++c) {
+        float run = 0.0f;                                        /* discounted_reward = 0          (:249) */
+        for (int32_t t = T - 1; t >= 0; --t) {                   /* for i in reversed(range(...))  (:250) */
+            const size_t i = (size_t)t * cols + c;
+            const float nd = 1.0f - (done[i] ? 1.0f : 0.0f);
+            const float gr = gamma * run;                        /* self.gamma * discounted_reward        */
+            run = reward[i] + gr * nd;                           /* rewards_b[i] + ... * (1 - dones_b[i]) (:251-253) */
+            returns[i] = run;                                    /* (:254) */
+            if (adv) adv[i] = values ? run - values[i] : run;    /* advantages = returns - values (:256) */
+        }
+    }
+}
+
+void syo_gae_f64(const double *reward, const uint8_t *done, const double *values, const double *last_value, int32_t T,
+                 int32_t cols, double gamma, double lam, double *adv, double *returns) {
+    for (int32_t c = 0; c < cols; ++c) {
+        double run = 0.0, nxt = last_value ? last_value[c] : 0.0;
+        for (int32_t t = T - 1; t >= 0; --t) {
+            const size_t i = (size_t)t * cols + c;
+            const double nd = 1.0 - (done[i] ? 1.0 : 0.0);
+            const double delta = (reward[i] + (gamma * nxt) * nd) - values[i];
+            run = delta + ((gamma * lam) * nd) * run;
+            adv[i] = run;
+            if (returns) returns[i] = run + values[i];
+            nxt = values[i];
+        }
+    }
+}

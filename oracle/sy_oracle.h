@@ -126,6 +126,18 @@ void syo_batch_rollout(const syo_batch_config *c, syo_graph *const *graphs, cons
                        const double *exp_tab, int32_t n_exp, const double *cov_tab, int32_t n_cov,
                        uint64_t seed, syo_traj *traj);
 
+/* agent/mappo_agent.py:247-258: reverse discounted reward sum with done masking over a flat buffer, float32 like
+ * the reference's tensors:  R_i = r_i + (gamma * R_{i+1}) * (1 - done_i)  (that operation order), adv = R - V.
+ * Batched over `cols` independent columns (element (t, c) at [t * cols + c]); values may be NULL (adv = R).
+ * Pinned by tests/golden/ppo_returns_reference.npz (captured from the unmodified ppo_update). */
+void syo_discounted_returns_f32(const float *reward, const uint8_t *done, const float *values, int32_t T, int32_t cols,
+                                float gamma, float *returns, float *adv);
+/* GAE(gamma, lambda), the generalisation the build adds (the reference has none):
+ * delta_t = r_t + gamma * V_{t+1} * (1 - d_t) - V_t;  A_t = delta_t + gamma * lambda * (1 - d_t) * A_{t+1};
+ * returns = A + V.  last_value [cols] bootstraps V_T (NULL = 0).  float64. */
+void syo_gae_f64(const double *reward, const uint8_t *done, const double *values, const double *last_value, int32_t T,
+                 int32_t cols, double gamma, double lam, double *adv, double *returns);
+
 #ifdef __cplusplus
 }
 #endif

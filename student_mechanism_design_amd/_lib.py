@@ -11,7 +11,9 @@ MAX_AGENTS = 8
 MAX_NODES = 1024
 NUM_WEIGHTS = 11
 MRX_MONEY = 1000
-ABI_VERSION = 2
+ABI_VERSION = 3
+STATUS_BELIEF_WAIT_EXPIRED = 1
+STATUS_RING_WAIT_EXPIRED = 2
 
 
 class EngineError(RuntimeError):
@@ -35,6 +37,17 @@ class MappoWeights(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("w1t", "b1", "w2t", "b2", "c1t", "cb1", "c2", "cb2", "w2")]
 
 
+class ReturnsArgs(C.Structure):
+    _fields_ = [("T", C.c_int32), ("B", C.c_int32), ("A", C.c_int32), ("mode", C.c_int32), ("reward", C.c_void_p),
+                ("reward_f64", C.c_int32), ("reward_stride_t", C.c_int64), ("reward_stride_b", C.c_int64),
+                ("done_a", C.c_void_p), ("done_b", C.c_void_p), ("done_bytes", C.c_int32),
+                ("done_stride_t", C.c_int64), ("done_stride_b", C.c_int64), ("value", C.c_void_p),
+                ("value_stride_t", C.c_int64), ("value_stride_b", C.c_int64), ("value_stride_a", C.c_int64),
+                ("last_value", C.c_void_p), ("last_value_stride_b", C.c_int64), ("last_value_stride_a", C.c_int64),
+                ("gamma", C.c_double), ("lam", C.c_double), ("compute_f64", C.c_int32), ("returns", C.c_void_p),
+                ("adv", C.c_void_p)]
+
+
 class RolloutBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("record", "mask", "belief", "log_prob")]
 
@@ -42,7 +55,8 @@ class RolloutBuffers(C.Structure):
 EXPORTS = ["sy_abi_version", "sy_record_words", "sy_last_error", "sy_env_create", "sy_env_destroy", "sy_env_launch_info",
            "sy_env_set_graph_pool", "sy_env_set_rewards", "sy_env_set_policy", "sy_env_bind_state", "sy_env_reset", "sy_env_reset_to",
            "sy_env_step", "sy_env_step_record", "sy_env_rollout", "sy_action_mask_dense", "sy_belief_update", "sy_build_apsp", "sy_sample_boards",
-           "sy_masked_categorical_sample", "sy_mappo_policy_act"]
+           "sy_masked_categorical_sample", "sy_mappo_policy_act", "sy_env_bind_status", "sy_env_status",
+           "sy_returns_advantages"]
 
 _lib = None
 
@@ -68,6 +82,9 @@ def load():
     lib.sy_env_set_rewards.argtypes = [vp, C.POINTER(C.c_double), vp, i32, vp, i32]
     lib.sy_env_bind_state.argtypes = [vp, C.POINTER(EnvState)]
     lib.sy_env_set_policy.argtypes = [vp, C.POINTER(MappoWeights), i32]
+    lib.sy_env_bind_status.argtypes = [vp, vp]
+    lib.sy_env_status.argtypes = [vp, vp, C.POINTER(C.c_uint32)]
+    lib.sy_returns_advantages.argtypes = [C.POINTER(ReturnsArgs), vp]
     lib.sy_env_reset.argtypes = [vp, vp, u64, vp]
     lib.sy_env_reset_to.argtypes = [vp, vp, vp]
     lib.sy_env_step.argtypes = [vp, vp, vp]

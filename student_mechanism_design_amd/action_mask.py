@@ -49,6 +49,10 @@ def compute_action_mask_batch(adjacency, current_nodes, budgets, tolls=None, edg
     if not torch.cuda.is_available():
         raise _lib.EngineError("compute_action_mask needs a GPU; there is no CPU fallback")
     device = torch.device(device)
+    if device.type != "cuda":
+        raise _lib.EngineError("compute_action_mask needs a cuda (ROCm) device")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
     adj = adjacency if isinstance(adjacency, torch.Tensor) else _dev(adjacency, device)
     adj = adj.to(device=device, dtype=torch.float64).contiguous()
     n = adj.shape[0]
@@ -61,10 +65,11 @@ def compute_action_mask_batch(adjacency, current_nodes, budgets, tolls=None, edg
     bud = torch.as_tensor(np.asarray(budgets, dtype=np.float64).reshape(-1)).to(device)
     q = cur.shape[0]
     mask = torch.empty((q, n), dtype=torch.uint8, device=device)
-    stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
     p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
-    _lib.check(lib.sy_action_mask_dense(p(adj), p(w), p(tl), n, p(cur), p(bud), q, p(mask), stream),
-               "sy_action_mask_dense")
+    with torch.cuda.device(device):               # launch on the tensors' device, with that device's stream
+        stream = C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+        _lib.check(lib.sy_action_mask_dense(p(adj), p(w), p(tl), n, p(cur), p(bud), q, p(mask), stream),
+                   "sy_action_mask_dense")
     return mask.view(torch.bool)
 
 

@@ -10,7 +10,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from .graph import make_board, pack_ell, inverse_degree, node_stride_for
+from ._lib import ELL_WIDTH
+from .graph import PAD_WEIGHT, node_stride_for
 
 
 class DeviceBeliefTracker:
@@ -19,6 +20,10 @@ class DeviceBeliefTracker:
         if not torch.cuda.is_available():
             raise _lib.EngineError("DeviceBeliefTracker needs a GPU; there is no CPU fallback")
         self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.EngineError("DeviceBeliefTracker needs a cuda (ROCm) device")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.num_nodes = int(num_nodes)
         self.NS = node_stride_for(num_nodes)
         self.Q = int(num_beliefs)
@@ -27,12 +32,27 @@ class DeviceBeliefTracker:
         self.reset()
 
     def set_adjacency(self, adjacency):
-        adj = np.asarray(adjacency)
+        """Rows are read exactly as the reference reads them (belief_module.py:88-96: a particle on node i moves to
+        a uniform element of nonzero(adjacency[i])): directed rows are kept directed, a non-zero diagonal entry is
+        a self-neighbour ("staying put"), an all-zero row keeps its particles.  The filter gathers over the
+        IN-neighbours of every node with weights 1 / out-degree: ell[j] lists {i : adjacency[i, j] != 0},
+        inv_deg[i] = 1 / |nonzero(adjacency[i])|.  At most 16 in-neighbours per node (ELL width)."""
+        adj = np.asarray(adjacency) != 0
         n = self.num_nodes
-        iu, ju = np.nonzero(np.triu((adj != 0) | (adj.T != 0), k=1))
-        board = make_board(n, np.stack([iu, ju], axis=1), np.ones(iu.shape[0], dtype=np.int64))
-        self.ell = torch.from_numpy(pack_ell(board).view(np.int32).copy()).to(self.device)
-        self.inv_deg = torch.from_numpy(inverse_degree(board, self.NS)).to(self.device)
+        if adj.shape != (n, n):
+            raise ValueError(f"adjacency must be [{n}, {n}]")
+        indeg = adj.sum(axis=0)
+        if indeg.max(initial=0) > ELL_WIDTH:
+            raise ValueError(f"a node has {int(indeg.max())} in-neighbours; the engine's ELL width is {ELL_WIDTH}")
+        ell = np.full((n, ELL_WIDTH), (PAD_WEIGHT << 16) | n, dtype=np.uint32)
+        for j in range(n):
+            src = np.nonzero(adj[:, j])[0]
+            ell[j, : src.shape[0]] = (np.uint32(1) << 16) | src.astype(np.uint32)
+        outdeg = adj.sum(axis=1)
+        inv = np.zeros(self.NS, dtype=np.float32)
+        inv[:n][outdeg > 0] = (1.0 / outdeg[outdeg > 0]).astype(np.float32)
+        self.ell = torch.from_numpy(ell.view(np.int32).copy()).to(self.device)
+        self.inv_deg = torch.from_numpy(inv).to(self.device)
 
     def reset(self, mr_x_position=None):
         """belief_module.py:57-67: uniform prior, or a delta when the position is known."""
@@ -65,7 +85,8 @@ class DeviceBeliefTracker:
             r = np.asarray(reveal, dtype=np.int32).reshape(-1)
             rev_t = torch.from_numpy(np.broadcast_to(r, (self.Q,)).copy()).to(self.device)
         p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _lib.check(self.lib.sy_belief_update(p(self.ell), p(self.inv_deg), self.num_nodes, self.NS, p(self._belief),
-                                             p(hint_t), hw, p(rev_t), self.Q, stream), "sy_belief_update")
+        with torch.cuda.device(self.device):      # the launch goes to the HIP current device: make it the tensors' device
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(self.lib.sy_belief_update(p(self.ell), p(self.inv_deg), self.num_nodes, self.NS, p(self._belief),
+                                                 p(hint_t), hw, p(rev_t), self.Q, stream), "sy_belief_update")
         return self.distribution()

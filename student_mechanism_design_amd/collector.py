@@ -9,9 +9,10 @@ src/training/mappo_trainer.py:161-287 / gnn_trainer.py:194-291).
 * `discounted_returns` / `standardized_advantages` — `MappoAgent.ppo_update`'s return and advantage
   maths (mappo_agent.py:247-258) over the time axis; `gae` is the lambda-generalisation that reduces
   to those returns at lambda = 1 with a zero bootstrap (the parity check SURVEY.md section 8a-13 names).
-* `gather_trajectories` — the ONE exchange of the multi-GPU path: the local record is packed into a
-  single byte buffer and all-gathered once (RCCL on GPU, gloo in the CPU tests); rollouts themselves
-  need no communication because episodes are independent.
+* `TrajectoryExchange` / `gather_trajectories` — the ONE exchange of the multi-GPU path, zero-copy: the rollout's
+  arena IS the send buffer, one `all_gather_into_tensor` into a preallocated `[world, bytes]` buffer, views out
+  (RCCL on GPU, gloo in the CPU tests); rollouts themselves need no communication because episodes are
+  independent.  `allreduce_gradients` is the cheaper data-parallel alternative (0.77 MB instead of GBs).
 """
 from typing import Callable, Dict, Optional
 
@@ -124,9 +125,82 @@ def gae(rewards, values, dones, last_value, gamma: float, lam: float):
     return adv, adv + values
 
 
+def device_returns(reward: torch.Tensor, done_a: torch.Tensor, gamma: float, done_b: Optional[torch.Tensor] = None,
+                   values: Optional[torch.Tensor] = None, lam: Optional[float] = None,
+                   last_value: Optional[torch.Tensor] = None, dtype: torch.dtype = torch.float32):
+    """Returns and advantages of a whole [T, B, A] rollout in ONE HIP launch (`sy_returns_advantages`,
+    include/sy_env.h) instead of a Python loop over T issuing ~5 torch kernels per step.
+
+    lam=None: the reference's recurrence, mappo_agent.py:247-258 — R_t = r_t + gamma * R_{t+1} * (1 - done_t),
+    adv = R - V; with dtype=float32 it reproduces the reference's float32 tensors bit for bit.
+    lam given: GAE(gamma, lam) with bootstrap `last_value`; returns = adv + V.
+    `reward` [T, B, A] float32/float64, any T / B strides (the packed record's `reward` view is read in place);
+    done = done_a | done_b, each [T, B] uint8 / bool / int32 (the record's `terminated`, `truncated`);
+    `values` [T, B] (central critic) or [T, B, A]; `last_value` [B] or [B, A].  Returns (returns, advantages),
+    contiguous [T, B, A] of `dtype` (float32 or float64).  No CPU fallback."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    dev = reward.device
+    if dev.type != "cuda":
+        raise _lib.EngineError("device_returns needs GPU tensors; there is no CPU fallback "
+                               "(`discounted_returns` / `gae` are the plain-torch forms)")
+    if reward.dim() != 3 or reward.stride(-1) != 1 or reward.dtype not in (torch.float32, torch.float64):
+        raise ValueError("reward must be float32/float64 [T, B, A] with a contiguous last dimension")
+    if dtype not in (torch.float32, torch.float64):
+        raise ValueError("dtype must be float32 or float64")
+    T, B, A = reward.shape
+
+    def flag(t, name):
+        if t is None:
+            return None
+        if t.dtype == torch.bool:
+            t = t.view(torch.uint8)
+        if t.dtype not in (torch.uint8, torch.int32) or tuple(t.shape) != (T, B) or t.device != dev:
+            raise ValueError(f"{name} must be uint8 / bool / int32 [T, B] on {dev}")
+        return t
+
+    da, db = flag(done_a, "done_a"), flag(done_b, "done_b")
+    if db is not None and (db.dtype != da.dtype or db.stride() != da.stride()):
+        db = db.to(da.dtype).contiguous()
+        da = da.contiguous()
+    vs = (0, 0, 0)
+    if values is not None:
+        values = values.to(device=dev, dtype=torch.float32)
+        if tuple(values.shape) == (T, B):
+            vs = (values.stride(0), values.stride(1), 0)
+        elif tuple(values.shape) == (T, B, A):
+            vs = tuple(values.stride())
+        else:
+            raise ValueError("values must be [T, B] or [T, B, A]")
+    lv = (0, 0)
+    if last_value is not None:
+        last_value = last_value.to(device=dev, dtype=torch.float32)
+        if tuple(last_value.shape) == (B,):
+            lv = (last_value.stride(0), 0)
+        elif tuple(last_value.shape) == (B, A):
+            lv = tuple(last_value.stride())
+        else:
+            raise ValueError("last_value must be [B] or [B, A]")
+    if lam is not None and values is None:
+        raise ValueError("GAE needs values")
+    ret = torch.empty((T, B, A), dtype=dtype, device=dev)
+    adv = torch.empty((T, B, A), dtype=dtype, device=dev)
+    p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+    args = _lib.ReturnsArgs(T, B, A, 0 if lam is None else 1, p(reward), 1 if reward.dtype == torch.float64 else 0,
+                            reward.stride(0), reward.stride(1), p(da), p(db), da.element_size(), da.stride(0), da.stride(1),
+                            p(values), vs[0], vs[1], vs[2], p(last_value), lv[0], lv[1], float(gamma),
+                            1.0 if lam is None else float(lam), 1 if dtype == torch.float64 else 0, p(ret), p(adv))
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.sy_returns_advantages(C.byref(args), stream), "sy_returns_advantages")
+    return ret, adv
+
+
 def pack_record(record: Dict[str, Optional[torch.Tensor]]):
-    """Flatten a rollout record {name: [T, B, ...]} into one uint8 buffer [B_total_bytes] per env-major
-    layout, plus the metadata needed to unpack it."""
+    """Generic fallback for records that are NOT arena-backed (plain dicts of separately allocated tensors):
+    flatten {name: [T, B, ...]} into one uint8 buffer plus the metadata to unpack it.  Costs one full copy;
+    `env.alloc_rollout` records never take this path."""
     names = sorted(k for k, v in record.items() if v is not None and k != "record")  # `record` aliases the named views
     parts, meta = [], []
     for k in names:
@@ -144,13 +218,61 @@ def unpack_record(buf: torch.Tensor, meta, world: int):
     off = 0
     for k, dtype, shape, nbytes in meta:
         pieces = [buf[r * per + off: r * per + off + nbytes].view(dtype).reshape(shape) for r in range(world)]
-        out[k] = torch.cat(pieces, dim=1)
+        out[k] = pieces[0] if world == 1 else torch.cat(pieces, dim=1)
         off += nbytes
     return out
 
 
+class TrajectoryExchange:
+    """The ONE exchange of the multi-GPU path (BASELINE configs[3]: "RCCL gather at PPO update"), zero-copy:
+
+    * the send buffer is the rollout's own arena (`env.alloc_rollout` carves every record tensor out of one
+      contiguous byte buffer), so nothing is packed;
+    * the receive buffer `[world, arena_bytes]` is allocated once and reused for every update;
+    * the result is a dict of VIEWS `[world, T, B_local, ...]` of that buffer (rank-major; a PPO update flattens
+      (world, T, B) anyway) — no `torch.cat`, no extra pass over the data.
+
+    One `all_gather_into_tensor` per update: RCCL over xGMI on GPU (a direct all-gather drives all 7 links of a
+    GPU at once), gloo in the CPU tests.  Cheaper alternative when every rank trains on its own shard: keep the
+    trajectories local and all-reduce the GRADIENTS (`allreduce_gradients`): 0.77 MB for the N=200 / H=64 MAPPO
+    networks instead of 2.06 GB per rank at T=256 — latency-bound, and the trajectories never move."""
+
+    def __init__(self, record, group=None):
+        if not hasattr(record, "arena"):
+            raise ValueError("TrajectoryExchange needs an arena-backed record (env.alloc_rollout)")
+        self.record, self.group = record, group
+        self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.nbytes = record.arena.numel()
+        self._recv = None
+
+    @property
+    def bytes_received_per_rank(self) -> int:
+        return (self.world - 1) * self.nbytes
+
+    def gather(self) -> Dict[str, torch.Tensor]:
+        from .env import RolloutRecord, record_fields
+        rec = self.record
+        if self.world == 1:
+            recv = rec.arena.view(1, -1)
+        else:
+            if self._recv is None:
+                self._recv = torch.empty(self.world * self.nbytes, dtype=torch.uint8, device=rec.arena.device)
+            dist.all_gather_into_tensor(self._recv, rec.arena, group=self.group)   # rank r's arena lands at r * nbytes
+            recv = self._recv.view(self.world, self.nbytes)
+        out = RolloutRecord.views_of(recv, rec.layout, lead=(self.world,))
+        A = rec["pos"].shape[-1]
+        out.update(record_fields(out["record"], A))
+        return out
+
+
 def gather_trajectories(record: Dict[str, Optional[torch.Tensor]], group=None):
-    """All ranks end up with the whole job's trajectories [T, world*B, ...]: ONE collective."""
+    """All ranks end up with the whole job's trajectories: ONE collective.
+
+    Arena-backed records (`env.alloc_rollout`): zero-copy, returns views [world, T, B_local, ...] (see
+    `TrajectoryExchange`; keep one exchange object alive to reuse its receive buffer across updates).
+    Plain dicts: packed once, gathered, returned as [T, world * B_local, ...] (legacy layout)."""
+    if hasattr(record, "arena"):
+        return TrajectoryExchange(record, group).gather()
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return {k: v for k, v in record.items() if v is not None and k != "record"}
     world = dist.get_world_size(group)
@@ -158,6 +280,26 @@ def gather_trajectories(record: Dict[str, Optional[torch.Tensor]], group=None):
     out = torch.empty(world * buf.numel(), dtype=torch.uint8, device=buf.device)
     dist.all_gather_into_tensor(out, buf, group=group)
     return unpack_record(out, meta, world)
+
+
+def allreduce_gradients(module: torch.nn.Module, group=None):
+    """The data-parallel alternative to gathering trajectories: every rank runs the PPO update on its own shard
+    and the gradients are averaged with ONE flat all-reduce (parameters of the MAPPO networks at N=200, H=64:
+    193 449 floats = 0.77 MB)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 0
+    grads = [p.grad for p in module.parameters() if p.grad is not None]
+    if not grads:
+        return 0
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dist.all_reduce(flat, group=group)
+    flat /= dist.get_world_size(group)
+    off = 0
+    for g in grads:
+        n = g.numel()
+        g.copy_(flat[off: off + n].view_as(g))
+        off += n
+    return flat.numel() * flat.element_size()
 
 
 class RolloutCollector:
@@ -176,9 +318,10 @@ class RolloutCollector:
                  record_mask: bool = True, record_belief: bool = True, use_graph: bool = False):
         self.env, self.policy, self.T = env, policy, int(frames_per_batch)
         self.record_mask, self.record_belief = record_mask, record_belief
-        self._buf = env.alloc_rollout(self.T, record_mask, record_belief)
-        B, A, dev = env.B, env.A, env.device
-        self._logp = torch.zeros((self.T, B, A), dtype=torch.float32, device=dev)
+        # log-probabilities and values live in the same arena as the record: one buffer to exchange
+        self._buf = env.alloc_rollout(self.T, record_mask, record_belief, log_prob=policy is not None,
+                                      value=policy is not None)
+        self._logp = self._buf.get("log_prob")
         self._value = None
         self.use_graph = bool(use_graph) and policy is not None
         self._graph = None
@@ -192,8 +335,9 @@ class RolloutCollector:
             if logp is not None:
                 self._logp[s].copy_(logp)
             if value is not None:
-                if self._value is None:
-                    self._value = torch.zeros((T,) + tuple(value.shape), dtype=torch.float32, device=env.device)
+                if self._value is None:      # central critic [B]: the arena's slot; per-agent values: own tensor
+                    self._value = self._buf["value"] if tuple(value.shape) == (env.B,) else \
+                        torch.zeros((T,) + tuple(value.shape), dtype=torch.float32, device=env.device)
                 self._value[s].copy_(value)
             # one kernel: the transition plus row s of the record (observation before the step, action, outcome)
             env.step_record(actions, buf, s)
@@ -203,7 +347,7 @@ class RolloutCollector:
         env, T, buf = self.env, self.T, self._buf
         if self.policy is None:
             env.rollout(T, out=buf, record=True)
-            return {k: v for k, v in buf.items() if v is not None}
+            return buf
         self._calls += 1
         if not self.use_graph or self._calls == 1:
             self._policy_loop()
@@ -215,8 +359,7 @@ class RolloutCollector:
                     self._policy_loop()            # recorded, not executed
                 self._graph = g
             self._graph.replay()
-        out = {k: v for k, v in buf.items() if v is not None}
-        out["log_prob"] = self._logp
+        out = buf if self._value is None or self._value is buf.get("value") else dict(buf)
         if self._value is not None:
             out["value"] = self._value
         return out

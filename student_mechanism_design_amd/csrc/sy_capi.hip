@@ -90,6 +90,16 @@ int sy_env_create(const sy_env_config* c, sy_env** out) {
         delete e;
         return fail(SY_ERR_INVALID, "board does not fit in LDS%s");
     }
+    // kernel-side cursors are 32-bit byte offsets (one uniform 64-bit base + a per-lane offset): reject batches
+    // whose per-step rows do not fit
+    {
+        const unsigned long long rowmax = 0xffffffffull;
+        if ((unsigned long long)p.B * p.NS * 4ull > rowmax || (unsigned long long)p.B * p.A * p.NS > rowmax ||
+            (unsigned long long)p.B * p.rec_words * 4ull > rowmax) {
+            delete e;
+            return fail(SY_ERR_INVALID, "num_envs * node_stride too large for one launch (a per-step row must stay below 4 GiB)%s");
+        }
+    }
     e->wpb = wpb;
     p.wpb = wpb;
     e->blocks = (p.B + wpb - 1) / wpb;
@@ -173,6 +183,29 @@ int sy_env_bind_state(sy_env* env, const sy_env_state* s) {
     env->p.st = *s;
     env->has_state = true;
     return SY_OK;
+}
+
+int sy_env_bind_status(sy_env* env, uint32_t* status) {
+    if (!env) return fail(SY_ERR_INVALID, "sy_env_bind_status: null env%s");
+    if (reinterpret_cast<uintptr_t>(status) & 3) return fail(SY_ERR_INVALID, "status word must be 4-byte aligned%s");
+    env->p.status = status;
+    return SY_OK;
+}
+
+int sy_env_status(sy_env* env, void* stream, uint32_t* status_host) {
+    if (!env) return fail(SY_ERR_INVALID, "sy_env_status: null env%s");
+    uint32_t w = 0;
+    if (env->p.status) {
+        hipError_t e = hipMemcpyAsync(&w, env->p.status, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+        if (e != hipSuccess) return hip_fail(e, "sy_env_status");
+    }
+    if (status_host) *status_host = w;
+    if (w == 0) return SY_OK;
+    std::snprintf(g_err, sizeof(g_err), "engine status 0x%x:%s%s results of the affected launch are invalid", w,
+                  (w & SY_STATUS_BELIEF_WAIT_EXPIRED) ? " a belief wave gave up waiting for its move wave;" : "",
+                  (w & SY_STATUS_RING_WAIT_EXPIRED) ? " a move wave gave up waiting for ring space;" : "");
+    return SY_ERR_HIP;
 }
 
 static int ready(const sy_env* env, const char* who) {
@@ -295,6 +328,25 @@ int sy_mappo_policy_act(const int32_t* pos, const uint8_t* mask, int64_t mask_ro
                                            num_envs, num_police + 1, num_nodes, hidden, seed, offset, offset_dev, action, log_prob,
                                            value, probs, (hipStream_t)stream);
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_mappo_policy_act launch");
+}
+
+int sy_returns_advantages(const sy_returns_args* a, void* stream) {
+    if (!a || !a->reward || !a->done_a || !a->returns) return fail(SY_ERR_INVALID, "sy_returns_advantages: null argument%s");
+    if (a->T < 1 || a->B < 1 || a->A < 1 || a->A > SY_MAX_AGENTS) return fail(SY_ERR_INVALID, "sy_returns_advantages: bad sizes%s");
+    if (a->mode != 0 && a->mode != 1) return fail(SY_ERR_INVALID, "sy_returns_advantages: mode must be 0 or 1%s");
+    if (a->done_bytes != 1 && a->done_bytes != 4) return fail(SY_ERR_INVALID, "sy_returns_advantages: done_bytes must be 1 or 4%s");
+    if (a->mode == 1 && !a->value) return fail(SY_ERR_INVALID, "sy_returns_advantages: GAE needs values%s");
+    if ((long long)a->B * a->A > 0x7fffffffLL) return fail(SY_ERR_INVALID, "sy_returns_advantages: too many columns%s");
+    sy::ReturnsArgs r;
+    r.T = a->T; r.B = a->B; r.A = a->A; r.mode = a->mode; r.reward_f64 = a->reward_f64 ? 1 : 0;
+    r.done_bytes = a->done_bytes; r.compute_f64 = a->compute_f64 ? 1 : 0;
+    r.reward = a->reward; r.rs_t = a->reward_stride_t; r.rs_b = a->reward_stride_b;
+    r.done_a = a->done_a; r.done_b = a->done_b; r.ds_t = a->done_stride_t; r.ds_b = a->done_stride_b;
+    r.value = a->value; r.vs_t = a->value_stride_t; r.vs_b = a->value_stride_b; r.vs_a = a->value_stride_a;
+    r.last_value = a->last_value; r.lv_b = a->last_value_stride_b; r.lv_a = a->last_value_stride_a;
+    r.gamma = a->gamma; r.lam = a->lambda; r.returns = a->returns; r.adv = a->adv;
+    hipError_t e = sy::launch_returns(r, (hipStream_t)stream);
+    return e == hipSuccess ? SY_OK : hip_fail(e, "sy_returns_advantages launch");
 }
 
 int sy_build_apsp(const uint32_t* ell, int32_t num_nodes, int32_t num_graphs, uint16_t* apsp, void* stream) {

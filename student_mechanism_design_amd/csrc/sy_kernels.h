@@ -36,6 +36,7 @@ struct EngineParams {
     const float* pw2;             // [A][N][H]
     const float* pb2;             // [A][N]
     int32_t pH;
+    uint32_t* status;             // device status word (sy_env_bind_status); nullptr = failures are not reported
 };
 #define SY_POLICY_SLICE 2304      // per-episode LDS scratch of the in-kernel policy: 8 hidden vectors of 64 floats + slots
 
@@ -57,6 +58,18 @@ hipError_t launch_sample_boards(int N, int NS, int E_target, int max_deg_extra, 
 hipError_t launch_masked_sample(const float* probs, long long probs_stride, const uint8_t* mask, long long mask_stride,
                                 int rows, int N, uint64_t seed, uint64_t offset, const uint64_t* offset_dev,
                                 int default_on_empty, int32_t* action, float* log_prob, float* norm_out, hipStream_t stream);
+
+// returns / advantages over a [T][B][A] rollout (sy_returns_advantages)
+struct ReturnsArgs {
+    int32_t T, B, A, mode, reward_f64, done_bytes, compute_f64;
+    const void* reward; long long rs_t, rs_b;
+    const void* done_a; const void* done_b; long long ds_t, ds_b;
+    const float* value; long long vs_t, vs_b, vs_a;
+    const float* last_value; long long lv_b, lv_a;
+    double gamma, lam;
+    void* returns; void* adv;
+};
+hipError_t launch_returns(const ReturnsArgs& a, hipStream_t stream);
 
 hipError_t launch_mappo_policy(const int32_t* pos, const uint8_t* mask, long long mask_row_stride, const float* w1t,
                                const float* b1, const float* w2t, const float* b2, const float* c1t, const float* cb1,

@@ -40,7 +40,10 @@ static constexpr int kPhiloxRounds = 7;
 static constexpr int kLdsTab = SY_LDS_TABLE;   // entries of the exp / coverage / reciprocal tables in LDS
 static constexpr int kAvgTab = SY_LDS_AVGTAB;  // entries of the -1/(sum/P+1) table in LDS
 static constexpr int kRing = SY_RING;          // move wave -> belief wave ring depth (steps)
-static constexpr int kSpinMax = 1 << 20;       // every spin is bounded: a lost partner cannot hang the GPU
+#ifndef SY_SPIN_MAX
+#define SY_SPIN_MAX (1 << 20)
+#endif
+static constexpr int kSpinMax = SY_SPIN_MAX;   // every spin is bounded: a lost partner cannot hang the GPU
 
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wave execute in order; this only stops the compiler from reordering
@@ -642,6 +645,14 @@ __device__ __forceinline__ KernargParams kernarg_params() {
     return q;
 }
 
+// A bounded spin that ran out is reported, not swallowed: the bit lands in the engine's status word (device memory
+// bound with sy_env_bind_status, read by sy_env_status), the launch still drains.  The pointer is re-read from the
+// kernel arguments on this cold path only.
+__device__ __forceinline__ void report_status(uint32_t bit) {
+    uint32_t* w = kernarg_params()->status;
+    if (w != nullptr && (threadIdx.x & 63) == 0) atomicOr(w, bit);
+}
+
 template <typename T>
 __device__ __forceinline__ T* at_bytes(T* base, uint32_t byte_off) {
     return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + byte_off);
@@ -924,7 +935,11 @@ __device__ __forceinline__ void belief_wave_run(const EngineParams& p, const Lds
                     for (int r = 0; r < NR; ++r)
                         if (lane + 64 * r < NS) *at_bytes(out.belief, off_bel + (uint32_t)(h * NS) * 4u + 256u * r) = b[r];
                 }
-                for (int spin = 0; lds_peek(Eh.sync) <= s && spin < kSpinMax; ++spin) __builtin_amdgcn_s_sleep(2);
+                {
+                    int spin = 0;
+                    for (; lds_peek(Eh.sync) <= s && spin < kSpinMax; ++spin) __builtin_amdgcn_s_sleep(2);
+                    if (spin == kSpinMax) report_status(SY_STATUS_BELIEF_WAIT_EXPIRED);
+                }
                 asm volatile("" ::: "memory");
                 const int4* ent = reinterpret_cast<const int4*>(Eh.ring + (s & (kRing - 1)) * 8);
                 const int4 e0v = ent[0], e1v = ent[1];
@@ -1129,7 +1144,11 @@ __global__ __launch_bounds__(768, SY_ROLLOUT_MIN_WAVES) void rollout_kernel(cons
             flags = 2;
         }
         if (has_belief) {
-            for (int spin = 0; s - lds_peek(E.sync + 1) >= kRing && spin < kSpinMax; ++spin) __builtin_amdgcn_s_sleep(2);
+            {
+                int spin = 0;
+                for (; s - lds_peek(E.sync + 1) >= kRing && spin < kSpinMax; ++spin) __builtin_amdgcn_s_sleep(2);
+                if (spin == kSpinMax) report_status(SY_STATUS_RING_WAIT_EXPIRED);
+            }
             asm volatile("" ::: "memory");
             int* slot_p = E.ring + (s & (kRing - 1)) * 8;
             if (ln < 8) slot_p[ln] = ln == 0 ? (pos_v | (flags << 16)) : (ln <= P ? pos_v : -1);
@@ -1285,7 +1304,11 @@ __device__ __forceinline__ void belief_pair_run(const EngineParams& p, const Lds
             }
         }
         // both ring entries of step s are published by one instruction of the pair's move wave
-        for (int spin = 0; lds_peek(E.sync) <= s && spin < kSpinMax; ++spin) __builtin_amdgcn_s_sleep(2);
+        {
+            int spin = 0;
+            for (; lds_peek(E.sync) <= s && spin < kSpinMax; ++spin) __builtin_amdgcn_s_sleep(2);
+            if (spin == kSpinMax) report_status(SY_STATUS_BELIEF_WAIT_EXPIRED);
+        }
         asm volatile("" ::: "memory");
         const int so = (s & (kRing - 1)) * 8;
         const int head0 = __builtin_amdgcn_readfirstlane(E.ring[so]), head1 = __builtin_amdgcn_readfirstlane(E1.ring[so]);
@@ -1977,17 +2000,23 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
             // back-pressure: every kRing/2 steps make sure the belief wave is at most kRing/2 entries behind,
             // so the ring can never be overrun in between (two fewer LDS round trips on the other steps)
             if ((s & (kRing / 2 - 1)) == 0) {
-                for (int spin = 0; spin < kSpinMax; ++spin) {
+                int spin = 0;
+                for (; spin < kSpinMax; ++spin) {
                     const int c0 = lds_peek(E.sync + 1), c1 = live1 ? lds_peek(E1.sync + 1) : s;
                     if (s - c0 <= kRing / 2 && s - c1 <= kRing / 2) break;
                     __builtin_amdgcn_s_sleep(2);
                 }
+                if (spin == kSpinMax) report_status(SY_STATUS_RING_WAIT_EXPIRED);
             }
             asm volatile("" ::: "memory");
             int* slot_p = ring_h + (s & (kRing - 1)) * 8;
             if (a < 8) slot_p[a] = a == 0 ? (pos_n | (flags_v << 16)) : (a <= P ? pos_n : -1);
             asm volatile("" ::: "memory");
+#ifdef SY_INJECT_LOST_HANDOFF   // fault-injection build (tests only): episode 0 stops publishing after step 2
+            if (a == 0 && !(eh == 0 && s >= 2)) lds_poke(sync_h, s + 1);
+#else
             if (a == 0) lds_poke(sync_h, s + 1);
+#endif
         }
         if (REC) {
             // the packed row straight from the agent lanes: five narrow stores into one 128-byte line
@@ -2615,6 +2644,69 @@ __global__ __launch_bounds__(1024) void mappo_policy_kernel(const int32_t* __res
 }
 
 // ---------------------------------------------------------------------------------------------
+// returns_kernel: the return / advantage lines of MappoAgent.ppo_update (agent/mappo_agent.py:247-258) for a whole
+// [T][B][A] rollout in ONE launch, and their GAE(gamma, lambda) generalisation.  One lane per (env, agent) column
+// walks the time axis backwards; the recurrence is sequential, the loads are not: U rows are fetched ahead of the
+// arithmetic (the record's reward / terminated / truncated words of one env-step share a 128-byte line).
+//   mode 0 (the reference):  R_t = r_t + (gamma * R_{t+1}) * (1 - d_t)   in exactly that operation order,
+//                            adv_t = R_t - V_t   (V = 0 when no values are given)
+//   mode 1 (GAE):            delta_t = (r_t + (gamma * V_{t+1}) * (1 - d_t)) - V_t
+//                            A_t = delta_t + ((gamma * lambda) * (1 - d_t)) * A_{t+1},   R_t = A_t + V_t
+// CT = float reproduces the reference's float32 tensors bit for bit; CT = double keeps the engine's float64 rewards.
+// ---------------------------------------------------------------------------------------------
+template <typename CT, typename RT, typename DT>
+__global__ __launch_bounds__(256) void returns_kernel(const ReturnsArgs a) {
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= a.B * a.A) return;
+    const int b = col / a.A, ag = col - b * a.A;
+    const RT* rp = reinterpret_cast<const RT*>(a.reward) + (long long)b * a.rs_b + ag;
+    const DT* da = reinterpret_cast<const DT*>(a.done_a) + (long long)b * a.ds_b;
+    const DT* db = a.done_b ? reinterpret_cast<const DT*>(a.done_b) + (long long)b * a.ds_b : nullptr;
+    const float* vp = a.value ? a.value + (long long)b * a.vs_b + (long long)ag * a.vs_a : nullptr;
+    const long long BA = (long long)a.B * a.A;
+    CT* ret = reinterpret_cast<CT*>(a.returns) + col;
+    CT* adv = a.adv ? reinterpret_cast<CT*>(a.adv) + col : nullptr;
+    const CT gamma = (CT)a.gamma, gl = (CT)a.gamma * (CT)a.lam;
+    CT run = (CT)0;
+    CT nxt = (a.mode == 1 && a.last_value) ? (CT)a.last_value[(long long)b * a.lv_b + (long long)ag * a.lv_a] : (CT)0;
+    constexpr int U = 16;
+    for (int t1 = a.T; t1 > 0; t1 -= U) {
+        CT r[U], nd[U], v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t1 - 1 - u;
+            const bool in = t >= 0;
+            const int tt = in ? t : 0;
+            r[u] = (CT)rp[(long long)tt * a.rs_t];
+            bool d = da[(long long)tt * a.ds_t] != 0;
+            if (db) d = d || db[(long long)tt * a.ds_t] != 0;
+            nd[u] = (CT)1 - (d ? (CT)1 : (CT)0);
+            v[u] = vp ? (CT)vp[(long long)tt * a.vs_t] : (CT)0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = t1 - 1 - u;
+            if (t < 0) continue;
+            CT R, A;
+            if (a.mode == 0) {
+                const CT gr = gamma * run;
+                run = r[u] + gr * nd[u];
+                R = run;
+                A = run - v[u];
+            } else {
+                const CT delta = (r[u] + (gamma * nxt) * nd[u]) - v[u];
+                run = delta + (gl * nd[u]) * run;
+                A = run;
+                R = run + v[u];
+                nxt = v[u];
+            }
+            ret[(long long)t * BA] = R;
+            if (adv) adv[(long long)t * BA] = A;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host-side launchers (called from the C ABI, sy_capi.hip)
 // ---------------------------------------------------------------------------------------------
 template <int NR>
@@ -2767,6 +2859,20 @@ hipError_t launch_mappo_policy(const int32_t* pos, const uint8_t* mask, long lon
     else SY_LAUNCH_MP(16);
 #undef SY_LAUNCH_MP
     return hipGetLastError();
+}
+
+template <typename CT>
+static hipError_t launch_returns_ct(const ReturnsArgs& a, hipStream_t stream) {
+    const int threads = 256, blocks = (a.B * a.A + threads - 1) / threads;
+#define SY_LAUNCH_RET(RT_, DT_) hipLaunchKernelGGL((returns_kernel<CT, RT_, DT_>), dim3(blocks), dim3(threads), 0, stream, a)
+    if (a.reward_f64) { if (a.done_bytes == 4) SY_LAUNCH_RET(double, int32_t); else SY_LAUNCH_RET(double, uint8_t); }
+    else { if (a.done_bytes == 4) SY_LAUNCH_RET(float, int32_t); else SY_LAUNCH_RET(float, uint8_t); }
+#undef SY_LAUNCH_RET
+    return hipGetLastError();
+}
+
+hipError_t launch_returns(const ReturnsArgs& a, hipStream_t stream) {
+    return a.compute_f64 ? launch_returns_ct<double>(a, stream) : launch_returns_ct<float>(a, stream);
 }
 
 }  // namespace sy

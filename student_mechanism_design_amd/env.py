@@ -43,6 +43,73 @@ def _stream_handle(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+def _splitmix64(x: int) -> int:
+    """One round of SplitMix64 (Steele et al. 2014): decorrelates consecutive reset epochs of one seed."""
+    m = 2**64 - 1
+    x = (x + 0x9E3779B97F4A7C15) & m
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & m
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & m
+    return x ^ (x >> 31)
+
+
+class RolloutRecord(dict):
+    """Rollout buffers {name: tensor}; every tensor is a view of `arena` (one contiguous uint8 device buffer).
+    `layout` = [(name, dtype, shape, byte offset, nbytes)] of the primary parts; `record_fields(rec)` gives the
+    named views of a packed record tensor."""
+
+    def __init__(self, arena: torch.Tensor, layout):
+        super().__init__()
+        self.arena, self.layout = arena, list(layout)
+        for name, dtype, shape, off, nbytes in self.layout:
+            self[name] = arena[off: off + nbytes].view(dtype).view(shape)
+
+    @staticmethod
+    def views_of(arena: torch.Tensor, layout, lead=()):
+        """The primary parts of an arena with extra leading dims `lead` (e.g. (world,) after an all-gather:
+        arena [world, nbytes]) as views — no copies."""
+        out = {}
+        for name, dtype, shape, off, nbytes in layout:
+            out[name] = arena[..., off: off + nbytes].view(dtype).view(tuple(lead) + tuple(shape))
+        return out
+
+
+def record_fields(rec: torch.Tensor, num_agents: int) -> Dict[str, torch.Tensor]:
+    """Named views of a packed record tensor [..., RW] (layout: include/sy_env.h)."""
+    A = int(num_agents)
+    return {"reward": rec[..., : 2 * A].view(torch.float64), "pos": rec[..., 2 * A: 3 * A],
+            "budget": rec[..., 3 * A: 4 * A], "action": rec[..., 4 * A: 5 * A], "t": rec[..., 5 * A],
+            "terminated": rec[..., 5 * A + 1], "truncated": rec[..., 5 * A + 2], "winner": rec[..., 5 * A + 3]}
+
+
+def record_words(num_agents: int) -> int:
+    """dwords per packed record row (mirror of sy_record_words, include/sy_env.h): 5A + 4 rounded up to 4."""
+    return (5 * int(num_agents) + 4 + 3) & ~3
+
+
+def make_rollout_record(T, B, A, NS, RW, device, mask=True, belief=True, log_prob=False, value=False) -> RolloutRecord:
+    """Carve the buffers of one rollout out of one contiguous byte arena (see `alloc_rollout`)."""
+    T = int(T)
+    parts = [("record", torch.int32, (T, B, RW))]
+    if mask:
+        parts.append(("mask", torch.uint8, (T, B, A, NS)))
+    if belief:
+        parts.append(("belief", torch.float32, (T, B, NS)))
+    if log_prob:
+        parts.append(("log_prob", torch.float32, (T, B, A)))
+    if value:
+        parts.append(("value", torch.float32, (T, B)))
+    layout, off = [], 0
+    for name, dtype, shape in parts:
+        nbytes = int(np.prod(shape)) * torch.empty((), dtype=dtype).element_size()
+        layout.append((name, dtype, shape, off, nbytes))
+        off = (off + nbytes + 255) // 256 * 256
+    buf = RolloutRecord(torch.zeros(off, dtype=torch.uint8, device=device), layout)
+    buf.update(record_fields(buf["record"], A))
+    for k in ("mask", "belief"):
+        buf.setdefault(k, None)
+    return buf
+
+
 class BatchedScotlandYardEnv:
     """B independent episodes stepped by one kernel launch.
 
@@ -75,6 +142,7 @@ class BatchedScotlandYardEnv:
         self.agent_money, self.max_timestep = int(agent_money), int(max_timestep)
         self.possible_agents = ["MrX"] + [f"Police{k}" for k in range(self.P)]
         self.seed = int(seed)
+        self.reset_epoch = 0          # seedless full resets since the last explicit seed (see `reset`)
         cfg = _lib.EnvConfig(self.B, self.N, self.P, self.agent_money, self.max_timestep, self.G, self.NS,
                              int(reveal_interval), int(bool(police_evidence)), int(bool(belief_init_onehot)),
                              int(bool(auto_reset)), int(waves_per_block), int(env_id_offset))
@@ -133,6 +201,9 @@ class BatchedScotlandYardEnv:
             self.pos, self.budget, self.t, self.step_count, self._visits, self._belief, self._mask, self.reward,
             self._terminated, self._truncated, self.winner)])
         _lib.check(self.lib.sy_env_bind_state(self._handle, C.byref(st)), "sy_env_bind_state")
+        # failure word: kernels OR a bit into it when a bounded in-kernel wait runs out (see `check_status`)
+        self._status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        _lib.check(self.lib.sy_env_bind_status(self._handle, _ptr(self._status)), "sy_env_bind_status")
         self.reset(seed=self.seed)
 
     # ------------------------------------------------------------------ housekeeping
@@ -146,6 +217,25 @@ class BatchedScotlandYardEnv:
             self.close()
         except Exception:
             pass
+
+    def status(self) -> int:
+        """The engine's device status word (SY_STATUS_* bits, include/sy_env.h).  Synchronises the current stream."""
+        w = C.c_uint32(0)
+        with torch.cuda.device(self.device):
+            self.lib.sy_env_status(self._handle, _stream_handle(self.device), C.byref(w))
+        return int(w.value)
+
+    def check_status(self):
+        """Raise `EngineError` if any launch since the last check reported an internal failure (a hand-off between
+        the move and belief waves of the fused rollout that ran out of its bounded wait): such a launch drains, but
+        its belief / record must not be trusted.  Call it at a host sync point (after a rollout batch, before an
+        update); it synchronises the current stream.  The word is cleared so that later launches are judged afresh."""
+        with torch.cuda.device(self.device):
+            rc = self.lib.sy_env_status(self._handle, _stream_handle(self.device), None)
+        if rc != 0:
+            msg = self.lib.sy_last_error().decode("utf-8", "replace")
+            self._status.zero_()
+            raise _lib.EngineError(msg)
 
     def set_reward_weights(self, reward_weights):
         """The 11 weights of reward_calculator.py (RewardWeightNet output, reward_net.py:5-17)."""
@@ -189,15 +279,39 @@ class BatchedScotlandYardEnv:
         }
 
     # ------------------------------------------------------------------ engine calls
+    @property
+    def stream_key(self) -> int:
+        """The Philox key the engine currently runs with: the seed itself after an explicit `reset(seed=...)`,
+        a SplitMix64 mix of (seed, reset epoch) after seedless full resets (what a checker must be keyed with)."""
+        if self.reset_epoch == 0:
+            return self.seed & (2**64 - 1)
+        return _splitmix64((self.seed + 0xD1B54A32D192ED03 * self.reset_epoch) & (2**64 - 1))
+
     def reset(self, seed: Optional[int] = None, env_mask: Optional[torch.Tensor] = None):
-        """CustomEnvironment.reset for all envs (or those selected by env_mask bool/uint8[B])."""
+        """CustomEnvironment.reset for all envs (or those selected by env_mask bool/uint8[B]).
+
+        RNG rule (engine-defined; the reference draws from numpy's global stream, yard.py:112-116):
+          * `reset(seed=s)`      restarts every stream: key = s, step counters zeroed — reproducible episodes.
+          * `reset()`            a NEW set of episodes, like the reference's reset: the reset epoch is mixed into the
+                                 key (`stream_key`), so start nodes and action draws differ from every earlier reset.
+          * `reset(env_mask=m)`  the selected envs restart from their own running counters (fresh starts); the key and
+                                 the other envs' streams are untouched.  A new seed cannot be combined with a mask: it
+                                 would re-key the envs that were not selected."""
+        if seed is not None and env_mask is not None:
+            raise ValueError("reset(seed=..., env_mask=...) would re-key the streams of the envs that are not selected; "
+                             "reseed with a full reset")
         if seed is not None:
             self.seed = int(seed)
+            self.reset_epoch = 0
+        elif env_mask is None:
+            self.reset_epoch += 1
         sel = None
         if env_mask is not None:
             sel = env_mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            if tuple(sel.shape) != (self.B,):
+                raise ValueError(f"env_mask must have shape ({self.B},)")
         with torch.cuda.device(self.device):   # launches go to the HIP current device
-            _lib.check(self.lib.sy_env_reset(self._handle, _ptr(sel), C.c_uint64(self.seed & (2**64 - 1)),
+            _lib.check(self.lib.sy_env_reset(self._handle, _ptr(sel), C.c_uint64(self.stream_key),
                                              _stream_handle(self.device)), "sy_env_reset")
         return self.observation()
 
@@ -222,6 +336,33 @@ class BatchedScotlandYardEnv:
             _lib.check(self.lib.sy_env_step(self._handle, _ptr(act), _stream_handle(self.device)), "sy_env_step")
         return self.observation(), self.reward, self.terminated, self.truncated
 
+    def _check_rollout_buffers(self, out: Dict[str, torch.Tensor], T: int, need_log_prob: bool = False):
+        """The C ABI receives raw pointers: a buffer that is too short, of another dtype / device or not contiguous
+        would be written past its end.  Every buffer must hold at least T rows of the engine's row shape."""
+        B, A, NS = self.B, self.A, self.NS
+        RW = int(self.lib.sy_record_words(A))
+        want = {"record": ((B, RW), torch.int32), "mask": ((B, A, NS), torch.uint8), "belief": ((B, NS), torch.float32),
+                "log_prob": ((B, A), torch.float32)}
+        if not isinstance(out, dict) or out.get("record") is None:
+            raise ValueError("a rollout record needs the packed `record` tensor (use alloc_rollout)")
+        if need_log_prob and out.get("log_prob") is None:
+            raise ValueError("a policy rollout needs a `log_prob` buffer")
+        for k, (shape, dtype) in want.items():
+            v = out.get(k)
+            if v is None:
+                continue
+            if not isinstance(v, torch.Tensor) or v.dtype != dtype:
+                raise ValueError(f"rollout buffer `{k}` must be a {dtype} tensor")
+            if v.device != self.device:
+                raise ValueError(f"rollout buffer `{k}` lives on {v.device}, the env on {self.device}")
+            if v.dim() != len(shape) + 1 or tuple(v.shape[1:]) != shape or v.shape[0] < T:
+                raise ValueError(f"rollout buffer `{k}` must have shape (>= {T}, {', '.join(map(str, shape))}), "
+                                 f"got {tuple(v.shape)}")
+            if not v.is_contiguous():
+                raise ValueError(f"rollout buffer `{k}` must be contiguous")
+        if out.get("belief") is not None and self._belief is None:
+            raise ValueError("this env tracks no belief (with_belief=False): pass belief=None")
+
     def step_record(self, actions: torch.Tensor, out: Dict[str, torch.Tensor], s: int):
         """`step` that also fills row `s` of a rollout record from `alloc_rollout` (observation before the
         step, packed outcome row) inside the same kernel: no copy launches in a policy-driven collector."""
@@ -231,8 +372,12 @@ class BatchedScotlandYardEnv:
             act = torch.as_tensor(actions).to(device=self.device, dtype=torch.int32).contiguous()
         if tuple(act.shape) != (self.B, self.A):
             raise ValueError(f"actions must have shape ({self.B}, {self.A})")
+        self._check_rollout_buffers(out, 1)
         if not 0 <= s < out["record"].shape[0]:
             raise IndexError("record row out of range")
+        for k in ("mask", "belief"):
+            if out.get(k) is not None and out[k].shape[0] <= s:
+                raise IndexError(f"`{k}` has no row {s}")
         row = _lib.RolloutBuffers(out["record"][s].data_ptr(),
                                   out["mask"][s].data_ptr() if out.get("mask") is not None else None,
                                   out["belief"][s].data_ptr() if out.get("belief") is not None else None, None)
@@ -241,23 +386,19 @@ class BatchedScotlandYardEnv:
                        "sy_env_step_record")
         return self.observation(), self.reward, self.terminated, self.truncated
 
-    def alloc_rollout(self, T: int, record_mask=True, record_belief=True) -> Dict[str, torch.Tensor]:
-        """Device buffers of one rollout.  `record` is the packed [T, B, RW] int32 tensor the engine
-        writes with one store per env-step (include/sy_env.h); the named entries are views of it."""
-        B, A, NS, dev = self.B, self.A, self.NS, self.device
-        RW = int(self.lib.sy_record_words(A))
-        rec = torch.zeros((T, B, RW), dtype=torch.int32, device=dev)
-        buf = {
-            "record": rec,
-            "reward": rec[..., : 2 * A].view(torch.float64),
-            "pos": rec[..., 2 * A: 3 * A], "budget": rec[..., 3 * A: 4 * A], "action": rec[..., 4 * A: 5 * A],
-            "t": rec[..., 5 * A], "terminated": rec[..., 5 * A + 1], "truncated": rec[..., 5 * A + 2],
-            "winner": rec[..., 5 * A + 3],
-            "mask": torch.empty((T, B, A, NS), dtype=torch.uint8, device=dev) if record_mask else None,
-            "belief": torch.empty((T, B, NS), dtype=torch.float32, device=dev)
-            if (record_belief and self._belief is not None) else None,
-        }
-        return buf
+    def alloc_rollout(self, T: int, record_mask=True, record_belief=True, log_prob: Optional[bool] = None,
+                      value: bool = False) -> "RolloutRecord":
+        """Device buffers of one rollout, carved out of ONE contiguous byte arena (`.arena`, uint8) so that the
+        multi-GPU exchange (`collector.gather_trajectories`) is a single collective on memory that already is the
+        send buffer — nothing is packed or copied.  `record` is the packed [T, B, RW] int32 tensor the engine
+        writes with one store per env-step (include/sy_env.h); `reward` ... `winner` are views of it; `mask`
+        [T, B, A, NS], `belief` [T, B, NS], `log_prob` [T, B, A] (default: when an in-kernel policy is set) and
+        `value` [T, B] (for policy-driven collectors) follow, each 256-byte aligned."""
+        if log_prob is None:
+            log_prob = self._policy is not None
+        return make_rollout_record(T, self.B, self.A, self.NS, int(self.lib.sy_record_words(self.A)), self.device,
+                                   mask=record_mask, belief=record_belief and self._belief is not None,
+                                   log_prob=log_prob, value=value)
 
     def set_policy(self, policy=None):
         """The reference's rollout loop with its own policy in it (mappo_trainer.py:161-287): after this call
@@ -280,10 +421,14 @@ class BatchedScotlandYardEnv:
         `set_policy`; returns the record."""
         if record and out is None:
             out = self.alloc_rollout(T, record_mask, record_belief)
+        T = int(T)
+        if T < 1:
+            raise ValueError("T must be >= 1")
         rb = None
         if record:
-            if self._policy is not None and out.get("log_prob") is None:
-                out["log_prob"] = torch.zeros((int(T), self.B, self.A), dtype=torch.float32, device=self.device)
+            if self._policy is not None and isinstance(out, dict) and out.get("log_prob") is None:
+                out["log_prob"] = torch.zeros((T, self.B, self.A), dtype=torch.float32, device=self.device)
+            self._check_rollout_buffers(out, T, need_log_prob=self._policy is not None)
             rb = _lib.RolloutBuffers(*[out[k].data_ptr() if out.get(k) is not None else None
                                        for k in ("record", "mask", "belief", "log_prob")])
         with torch.cuda.device(self.device):

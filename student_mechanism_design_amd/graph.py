@@ -48,9 +48,30 @@ def make_board(num_nodes, edge_links, edge_weights) -> Board:
     return Board(np.arange(num_nodes, dtype=np.int64), w, links)
 
 
-def sample_board(num_nodes=10, num_edges=None, max_edges_per_node=4, rng=None) -> Board:
-    """graph_layout.py:9-52 with a numpy Generator."""
+def sample_board(num_nodes=10, num_edges=None, max_edges_per_node=4, rng=None, max_redraws=100) -> Board:
+    """graph_layout.py:9-52 with a numpy Generator.  The random-Prim tree puts no cap on a node's degree
+    (graph_layout.py:54-80); a board with a node of more than 16 neighbours cannot be packed (`pack_ell`), so
+    such a draw is rejected and redrawn here (probability ~1e-9 per node at N=200) instead of failing later."""
     rng = rng if rng is not None else np.random.default_rng()
+    for _ in range(max_redraws):
+        b = _sample_board_once(num_nodes, num_edges, max_edges_per_node, rng)
+        if max_degree(b) <= ELL_WIDTH:
+            return b
+    raise RuntimeError(f"board sampler: no board with max degree <= {ELL_WIDTH} in {max_redraws} draws")
+
+
+def max_degree(board: Board) -> int:
+    """Widest neighbour row (distinct neighbours; parallel edges collapse, yard.py:460-465)."""
+    if board.num_edges == 0:
+        return 0
+    lo = np.minimum(board.edge_links[:, 0], board.edge_links[:, 1]).astype(np.int64)
+    hi = np.maximum(board.edge_links[:, 0], board.edge_links[:, 1]).astype(np.int64)
+    uniq = np.unique(lo * board.num_nodes + hi)
+    deg = np.bincount(np.concatenate([uniq // board.num_nodes, uniq % board.num_nodes]), minlength=board.num_nodes)
+    return int(deg.max())
+
+
+def _sample_board_once(num_nodes, num_edges, max_edges_per_node, rng) -> Board:
     n = int(num_nodes)
     # _create_tree (graph_layout.py:54-80): an edge drawn uniformly from visited x unvisited is a
     # uniform visited endpoint and, independently, a uniform unvisited endpoint.
@@ -194,13 +215,16 @@ def device_all_pairs_shortest_paths(ell, num_nodes: int, device="cuda"):
     if not torch.cuda.is_available():
         raise _lib.EngineError("device_all_pairs_shortest_paths needs a GPU; use all_pairs_shortest_paths on the host")
     dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     ell_t = ell if isinstance(ell, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(ell).view(np.int32).copy())
     ell_t = ell_t.to(dev).contiguous()
     G = ell_t.shape[0]
     out = torch.empty((G, num_nodes, num_nodes), dtype=torch.int16, device=dev)
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-    _lib.check(lib.sy_build_apsp(C.c_void_p(ell_t.data_ptr()), int(num_nodes), int(G), C.c_void_p(out.data_ptr()), stream),
-               "sy_build_apsp")
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.sy_build_apsp(C.c_void_p(ell_t.data_ptr()), int(num_nodes), int(G), C.c_void_p(out.data_ptr()), stream),
+                   "sy_build_apsp")
     return out
 
 
@@ -239,6 +263,36 @@ class DevicePool:
                           self.inv_deg.cpu().numpy())
 
 
+def sample_boards_device_raw(num_graphs, num_nodes, num_edges, seed=0, max_edges_per_node=4, device="cuda"):
+    """One `sy_sample_boards` launch, no redraws: independent draws of ConnectedGraph.sample's process on the GPU.
+    Returns host arrays (edge_links int32 [G, E, 2], edge_w int32 [G, E], edges_realised int32 [G]; -1 = a node
+    exceeded the ELL width) — boards keep their own realised edge counts, as the reference's sampler does before
+    `yard.py:90-101` filters them."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    lib = _lib.load()
+    if not torch.cuda.is_available():
+        raise _lib.EngineError("sample_boards_device_raw needs a GPU; use sample_board on the host")
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    G, N = int(num_graphs), int(num_nodes)
+    NS = node_stride_for(N)
+    E = max(int(num_edges) if num_edges is not None else N - 1, N - 1)
+    ell = torch.empty((G, N, ELL_WIDTH), dtype=torch.int32, device=dev)
+    inv_deg = torch.empty((G, NS), dtype=torch.float32, device=dev)
+    links = torch.zeros((G, E, 2), dtype=torch.int32, device=dev)
+    w = torch.zeros((G, E), dtype=torch.int32, device=dev)
+    counts = torch.empty((G,), dtype=torch.int32, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
+    with torch.cuda.device(dev):
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        _lib.check(lib.sy_sample_boards(N, NS, E, int(max_edges_per_node), C.c_uint64(int(seed) & (2**64 - 1)), G, p(ell),
+                                        p(inv_deg), p(links), p(w), p(counts), E, stream), "sy_sample_boards")
+    return links.cpu().numpy(), w.cpu().numpy(), counts.cpu().numpy()
+
+
 def sample_board_pool_device(num_graphs, num_nodes, num_edges, seed=0, max_edges_per_node=4, max_attempts=100,
                              device="cuda") -> DevicePool:
     """`sample_board_pool` on the GPU: boards with one common edge count (yard.py:65-101 — the first
@@ -251,6 +305,8 @@ def sample_board_pool_device(num_graphs, num_nodes, num_edges, seed=0, max_edges
     if not torch.cuda.is_available():
         raise _lib.EngineError("sample_board_pool_device needs a GPU; use sample_board_pool on the host")
     dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
     G, N = int(num_graphs), int(num_nodes)
     NS = node_stride_for(N)
     E = max(int(num_edges) if num_edges is not None else N - 1, N - 1)
@@ -259,7 +315,6 @@ def sample_board_pool_device(num_graphs, num_nodes, num_edges, seed=0, max_edges
     links = torch.zeros((G, E, 2), dtype=torch.int32, device=dev)
     w = torch.zeros((G, E), dtype=torch.int32, device=dev)
     counts = torch.empty((G,), dtype=torch.int32, device=dev)
-    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
     p = lambda t: C.c_void_p(t.data_ptr())  # noqa: E731
 
     def draw(n, s):
@@ -267,6 +322,7 @@ def sample_board_pool_device(num_graphs, num_nodes, num_edges, seed=0, max_edges
                               for t in (ell, inv_deg, links, w, counts))
         l_.zero_(); w_.zero_()
         with torch.cuda.device(dev):
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
             _lib.check(lib.sy_sample_boards(N, NS, E, int(max_edges_per_node), C.c_uint64(s & (2**64 - 1)), n, p(e_), p(i_),
                                             p(l_), p(w_), p(c_), E, stream), "sy_sample_boards")
         return e_, i_, l_, w_, c_

@@ -17,9 +17,16 @@ def belief_cross_entropy(belief: torch.Tensor, true_index: torch.Tensor) -> torc
     return -torch.log(torch.gather(b, -1, true_index.long().unsqueeze(-1)).squeeze(-1))
 
 
-def rollout_metrics(record: Dict[str, torch.Tensor], num_nodes: int) -> Dict[str, torch.Tensor]:
+def rollout_metrics(record: Dict[str, torch.Tensor], num_nodes: int, reveal_interval: int = 0) -> Dict[str, torch.Tensor]:
     """Aggregates over the episodes that END inside the record (winner: 1 Police, 2 MrX).
-    Episode length = the env timestep at the finishing step + 1 (= number of steps played)."""
+    Episode length = the env timestep at the finishing step + 1 (= number of steps played).
+
+    Belief quality follows `MetricsTracker.record_step` (eval/metrics.py:138-141): the cross-entropy is taken AT
+    REVEAL TIMES only — with `reveal_interval` = k, at the rows whose step ends with a reveal ((t + 1) % k == 0):
+    the police's belief just before MrX shows himself, scored against where he stands.  `mean_belief_ce_all_steps`
+    is the average over every recorded step (what round 1 reported under the reference's name).
+    `mean_budget_before_final_step` is the police budget in the observation of the finishing step (the record
+    holds observations BEFORE each step; the last move's debit is not part of it)."""
     done = (record["terminated"] | record["truncated"]).bool()
     winner = record["winner"]
     length = (record["t"] + 1).float()
@@ -33,10 +40,19 @@ def rollout_metrics(record: Dict[str, torch.Tensor], num_nodes: int) -> Dict[str
         "mean_episode_length": (length * done).sum() / n,
         "mean_time_to_catch": (length * pol).sum() / pol.sum().clamp_min(1).float(),
         "mean_survival_time": (length * mrx).sum() / mrx.sum().clamp_min(1).float(),
-        "mean_budget_left": (record["budget"][..., 1:].float().mean(-1) * done).sum() / n,
+        "mean_budget_before_final_step": (record["budget"][..., 1:].float().mean(-1) * done).sum() / n,
     }
     if record.get("belief") is not None:
         ce = belief_cross_entropy(record["belief"][..., :num_nodes], record["pos"][..., 0])
-        out["mean_belief_ce"] = ce.mean()
-        out["belief_ce_std"] = ce.std(unbiased=False)                          # np.std, metrics.py:199
+        out["mean_belief_ce_all_steps"] = ce.mean()
+        if reveal_interval and reveal_interval > 0:
+            at_reveal = (record["t"] + 1) % int(reveal_interval) == 0
+            k = at_reveal.sum().clamp_min(1).float()
+            mean = (ce * at_reveal).sum() / k
+            out["num_reveals"] = at_reveal.sum()
+            out["mean_belief_ce"] = mean                                        # metrics.py:138-141,198
+            out["belief_ce_std"] = (((ce - mean) ** 2 * at_reveal).sum() / k).sqrt()   # np.std, metrics.py:199
+        else:
+            out["mean_belief_ce"] = ce.mean()
+            out["belief_ce_std"] = ce.std(unbiased=False)
     return out

@@ -4,7 +4,9 @@
 `src/environment/yard.py::CustomEnvironment` so per-env code (trainers, tests) can call it unchanged;
 every transition runs on the GPU through `BatchedScotlandYardEnv` (one env, one wave).  It exists
 for drop-in compatibility and for replaying golden traces through the public surface — throughput
-comes from the batched class.  `as_tensordict` gives the nested key layout `src/training` reads
+comes from the batched class: a facade `reset()` builds a fresh one-env engine (board upload, ~12 small
+allocations) and every `step()` reads the state back to the host (>= 6 blocking copies), i.e. it is
+millisecond-scale per call by construction.  `as_tensordict` gives the nested key layout `src/training` reads
 through torchrl's wrapper (level 2; torchrl itself is absent offline — parity unpinned).
 """
 from types import SimpleNamespace
@@ -46,6 +48,7 @@ class CustomEnvironment:
         self._device, self._reveal = device, int(reveal_interval)
         self._rng = np.random.default_rng(seed)
         self._seed = int(seed)
+        self._resets = 0          # every reset() draws new start nodes, like the reference (yard.py:112-116)
         self._env = None
         # yard.py:65-76: the first sample fixes the achievable edge count
         reference_board = sample_board(self.graph_nodes, self.graph_edges, rng=self._rng)
@@ -71,7 +74,8 @@ class CustomEnvironment:
             self._env.close()
         self._env = BatchedScotlandYardEnv(1, [board], self.number_of_agents, self.agent_money, self.reward_weights,
                                            auto_reset=False, reveal_interval=self._reveal, device=self._device,
-                                           seed=self._seed + int(episode), waves_per_block=1)
+                                           seed=self._seed + int(episode) + 1000003 * self._resets, waves_per_block=1)
+        self._resets += 1
         if options.get("starts") is not None:
             self._env.reset_to(np.asarray(options["starts"], dtype=np.int32).reshape(1, -1))
         self.agents = list(self.possible_agents)

@@ -9,6 +9,8 @@ import torch.multiprocessing as mp
 
 from student_mechanism_design_amd import collector as col
 
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
 
 def _select_action_goldens():
     import json
@@ -145,6 +147,82 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _arena_record(rank, T=4, B=3, A=3, NS=16):
+    from student_mechanism_design_amd.env import make_rollout_record, record_words
+    rec = make_rollout_record(T, B, A, NS, record_words(A), "cpu", log_prob=True, value=True)
+    g = torch.Generator().manual_seed(200 + rank)
+    rec.arena.copy_(torch.randint(0, 256, (rec.arena.numel(),), generator=g, dtype=torch.uint8))
+    return rec
+
+
+def _worker_arena(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rec = _arena_record(rank)
+        ex = col.TrajectoryExchange(rec)
+        ok = ex.world == world and ex.bytes_received_per_rank == (world - 1) * rec.arena.numel()
+        for rep in range(2):                       # the receive buffer is reused across updates
+            out = ex.gather()
+            recv_ptr = ex._recv.data_ptr()
+            for r in range(world):
+                ref = _arena_record(r)
+                for k, v in ref.items():
+                    if v is None:
+                        continue
+                    got = out[k][r]
+                    ok = ok and got.shape == v.shape and got.dtype == v.dtype
+                    ok = ok and torch.equal(got.contiguous().view(torch.uint8), v.contiguous().view(torch.uint8))
+                    # views of the receive buffer, not copies
+                    ok = ok and recv_ptr <= out[k].data_ptr() < recv_ptr + ex._recv.numel()
+            ok = ok and out["pos"].shape[:2] == (world, 4)
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_zero_copy_trajectory_exchange_gloo_world2():
+    """The exchange of BASELINE configs[3] ("gather at PPO update") on arena-backed records: the arena is the
+    send buffer, one all-gather into a reused [world, bytes] buffer, results are views of it."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_arena, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, True), (1, True)]
+
+
+def test_arena_record_layout_and_single_rank_gather():
+    from student_mechanism_design_amd.env import make_rollout_record, record_words
+    T, B, A, NS = 5, 4, 5, 32
+    rec = make_rollout_record(T, B, A, NS, record_words(A), "cpu", log_prob=True)
+    lo, hi = rec.arena.data_ptr(), rec.arena.data_ptr() + rec.arena.numel()
+    for k, v in rec.items():
+        if v is not None:
+            assert lo <= v.data_ptr() < hi, k                        # every tensor is a view of the arena
+    for name, dtype, shape, off, nbytes in rec.layout:
+        assert off % 256 == 0 and rec[name].is_contiguous()
+    rec["pos"][2, 1, 3] = 77
+    assert int(rec["record"][2, 1, 2 * A + 3]) == 77                 # named fields alias the packed row
+    rec["reward"][1, 0, 4] = -0.25
+    assert rec["record"][1, 0, 8:10].view(torch.float64).item() == -0.25
+    out = col.gather_trajectories(rec)                                # world 1: views of the arena itself
+    assert out["pos"].shape == (1, T, B, A) and int(out["pos"][0, 2, 1, 3]) == 77
+    assert out["mask"].data_ptr() == rec["mask"].data_ptr()
+
+
+def test_allreduce_gradients_is_identity_without_a_group():
+    lin = torch.nn.Linear(3, 2)
+    lin(torch.ones(1, 3)).sum().backward()
+    g = lin.weight.grad.clone()
+    assert col.allreduce_gradients(lin) == 0 and torch.equal(lin.weight.grad, g)
+
+
 def test_gather_trajectories_gloo_world2():
     """The N>1 path: env shards are independent, one all-gather of the packed record at the update."""
     ctx = mp.get_context("spawn")
@@ -176,3 +254,28 @@ def test_env_shards_use_disjoint_rng_streams():
         rp = part.rollout(30)
         for k in ("pos", "action", "reward", "terminated"):
             np.testing.assert_array_equal(rp[k], rw[k][:, 8 * r:8 * (r + 1)], err_msg=k)
+
+
+def test_returns_and_advantages_match_the_unmodified_ppo_update():
+    """tests/golden/ppo_returns_reference.npz: what mappo_agent.py:247-258 computes inside the unmodified
+    `MappoAgent.ppo_update` (oracle/capture_ppo_returns.py).  The oracle's C restatement is bit-exact; the torch
+    forms (`discounted_returns`, `standardized_advantages`) agree to float32 rounding of a different op order."""
+    from oracle import oracle_lib as ol
+    z = np.load(os.path.join(GOLDEN, "ppo_returns_reference.npz"))
+    assert len(z["case_names"]) >= 7
+    for name in z["case_names"]:
+        r32 = z[f"{name}/reward"].astype(np.float32)
+        d, gamma, val = z[f"{name}/done"], float(z[f"{name}/gamma"]), z[f"{name}/values"]
+        ret, adv = ol.discounted_returns_f32(r32, d, gamma, val)
+        np.testing.assert_array_equal(ret, z[f"{name}/returns"], err_msg=name)          # bit-exact float32
+        t_ret = col.discounted_returns(torch.tensor(r32), torch.tensor(d), gamma)
+        np.testing.assert_allclose(t_ret.numpy(), z[f"{name}/returns"], rtol=2e-6, atol=2e-6, err_msg=name)
+        t_adv = col.standardized_advantages(torch.tensor(z[f"{name}/returns"]), torch.tensor(val))
+        np.testing.assert_allclose(t_adv.numpy(), z[f"{name}/advantages"], rtol=1e-6, atol=1e-6, err_msg=name)
+        # GAE at lambda = 1 with a zero bootstrap reduces to the reference's returns (SURVEY 8a-13)
+        g_adv, g_ret = ol.gae_f64(z[f"{name}/reward"], d, val.astype(np.float64), gamma, 1.0)
+        run, want = 0.0, np.zeros(len(r32))
+        for i in range(len(r32) - 1, -1, -1):
+            run = z[f"{name}/reward"][i] + gamma * run * (1.0 - d[i])
+            want[i] = run
+        np.testing.assert_allclose(g_ret, want, rtol=1e-12, atol=1e-12, err_msg=name)

@@ -293,6 +293,58 @@ def test_full_size_properties(sy):
 
 
 # ----------------------------------------------------------------------------------------------
+# Every benchmarked shape against the oracle AT ITS OWN SIZE: the bench.py workload (BASELINE configs[1]:
+# same boards, weights, seed, block size, fused length T = 256 — the Philox step counter passes 255 and
+# hundreds of episodes restart inside the launch) and the per-GPU shards of configs[3] / configs[4].
+# The oracle (OpenMP over envs) does each in about a second.
+# ----------------------------------------------------------------------------------------------
+FULL_SIZE_CASES = {
+    "configs1_bench": dict(B=4096, N=200, E=400, P=4, money=20, G=8, env_seed=1234, env_id_offset=0, T=256),
+    "configs3_shard_rank3": dict(B=4096, N=200, E=400, P=6, money=20, G=8, env_seed=1234, env_id_offset=3 * 4096, T=256),
+    "configs4_shard_rank5": dict(B=8192, N=199, E=400, P=5, money=20, G=8, env_seed=1234, env_id_offset=5 * 8192, T=256),
+}
+
+
+def compare_rollout_with_oracle(rec, ref, T, chunk=32):
+    """Record of T fused steps vs the oracle's, compared in time slices (bounded host memory)."""
+    for s0 in range(0, T, chunk):
+        s1 = min(T, s0 + chunk)
+        for k in ("pos", "t", "action", "terminated", "truncated", "winner", "mask", "reward"):
+            np.testing.assert_array_equal(_np(rec[k][s0:s1]), ref[k][s0:s1], err_msg=f"{k} steps {s0}..{s1}")
+        np.testing.assert_array_equal(_np(rec["budget"][s0:s1]), ref["money"][s0:s1], err_msg=f"budget steps {s0}..{s1}")
+        if rec.get("belief") is not None:
+            d = np.abs(_np(rec["belief"][s0:s1]).astype(np.float64) - ref["belief"][s0:s1]).max()
+            assert d <= BELIEF_TOL, f"belief steps {s0}..{s1}: max abs diff {d}"
+
+
+@pytest.mark.parametrize("name", list(FULL_SIZE_CASES))
+def test_benchmarked_shape_matches_oracle_at_full_size(sy, ol, name):
+    c = FULL_SIZE_CASES[name]
+    B, N, P, T = c["B"], c["N"], c["P"], c["T"]
+    boards = sy.sample_board_pool(c["G"], N, c["E"], seed=0)            # bench.py's boards
+    weights = np.full(11, 0.5)                                          # bench.py's weights
+    env = sy.BatchedScotlandYardEnv(B, boards, P, c["money"], weights, seed=c["env_seed"], reveal_interval=5,
+                                    env_id_offset=c["env_id_offset"])
+    assert env.waves_per_block == 16                                    # the default block size the bench runs
+    graphs = [ol.OracleGraph(N, b.edge_links, b.edges.astype(np.int32)) for b in boards]
+    orc = ol.OracleBatch(graphs, env.env_graph_host, B, P, c["money"], node_stride=env.NS, weights=weights,
+                         tables=sy.reward_tables(), reveal_interval=5, env_id_offset=c["env_id_offset"],
+                         threads=max(1, len(os.sched_getaffinity(0))))
+    orc.reset(seed=c["env_seed"])
+    _compare_state(env, orc, "after reset")
+    out = env.alloc_rollout(T)
+    for launch in range(2):            # the second launch continues from the live state, like the bench's timed loop
+        rec = env.rollout(T, out=out)
+        ref = orc.rollout(T)
+        compare_rollout_with_oracle(rec, ref, T)
+        _compare_state(env, orc, f"after launch {launch}")
+        done = ref["terminated"] | ref["truncated"]
+        assert done.sum() > B // 4, "restarts inside a launch must be exercised at scale"
+        del ref
+    env.close()
+
+
+# ----------------------------------------------------------------------------------------------
 # action-mask known answers and belief filter through their own entry points
 # ----------------------------------------------------------------------------------------------
 def test_action_mask_known_answers_on_device(sy):
@@ -360,13 +412,16 @@ def test_errors_are_reported_not_thrown_across_the_abi(sy):
         sy.BatchedScotlandYardEnv(4, [sy.sample_board(10, 14, rng=np.random.default_rng(0))], 2, 10, np.zeros(5))
 
 
-def test_device_apsp_matches_host_and_reference_distances(sy):
-    """sy_build_apsp (Bellman-Ford per source on the GPU) == host Floyd-Warshall == the reference's
-    Dijkstra distances (they feed the golden float64 rewards) — bit-exact integers."""
-    boards = sy.sample_board_pool(5, 200, 400, seed=9) 
+def test_device_apsp_matches_host_and_reference_distances(sy, ol):
+    """sy_build_apsp (Bellman-Ford per source on the GPU) == the ORACLE's shortest paths (`OracleGraph.dist`,
+    pinned to the reference's Dijkstra by the golden float64 rewards) == host Floyd-Warshall — bit-exact integers."""
+    boards = sy.sample_board_pool(5, 200, 400, seed=9)
     pool = sy.pack_pool(boards)
     dev = sy.device_all_pairs_shortest_paths(pool.ell, 200)
     np.testing.assert_array_equal(_np(dev).view(np.uint16), pool.apsp)
+    for g, b in enumerate(boards):       # directly against the checker, not through product code
+        og = ol.OracleGraph(200, b.edge_links, b.edges.astype(np.int32))
+        np.testing.assert_array_equal(_np(dev)[g].view(np.uint16).astype(np.int32), og.dist)
     for n, e, seed in ((15, 20, 1), (64, 63, 2), (130, 250, 3), (520, 1000, 4)):
         bs = sy.sample_board_pool(2, n, e, seed=seed)
         pk = sy.pack_pool(bs)
@@ -374,8 +429,9 @@ def test_device_apsp_matches_host_and_reference_distances(sy):
     # golden board (N=200 reference trace) and a disconnected board (0xFFFF = unreachable)
     tr = load_trace("trace_s10_n200_p4_m20_random_valid_ep0.npz")
     b = sy.make_board(200, tr["edge_links"], tr["edge_w"])
-    np.testing.assert_array_equal(_np(sy.device_all_pairs_shortest_paths(sy.pack_ell(b)[None], 200))[0].view(np.uint16),
-                                  sy.all_pairs_shortest_paths(b))
+    d200 = _np(sy.device_all_pairs_shortest_paths(sy.pack_ell(b)[None], 200))[0].view(np.uint16)
+    np.testing.assert_array_equal(d200, sy.all_pairs_shortest_paths(b))
+    np.testing.assert_array_equal(d200.astype(np.int32), ol.OracleGraph(200, tr["edge_links"], tr["edge_w"].astype(np.int32)).dist)
     two = sy.make_board(6, [[0, 1], [1, 2], [3, 4]], [2, 3, 1])
     d = _np(sy.device_all_pairs_shortest_paths(sy.pack_ell(two)[None], 6))[0].view(np.uint16)
     assert d[0, 2] == 5 and d[3, 4] == 1 and d[0, 3] == 0xFFFF and d[5, 0] == 0xFFFF and d[5, 5] == 0
@@ -411,9 +467,11 @@ def test_rollout_metrics_on_device(sy):
     boards = sy.sample_board_pool(2, 60, 100, seed=3)
     env = sy.BatchedScotlandYardEnv(512, boards, 4, 12, np.full(11, 0.5), seed=1, reveal_interval=5)
     rec = env.rollout(96)
-    m = M.rollout_metrics(rec, env.N)
+    m = M.rollout_metrics(rec, env.N, reveal_interval=5)
     done = (_np(rec["terminated"]) | _np(rec["truncated"])).astype(bool)
     assert int(m["num_episodes"]) == done.sum() > 0
+    assert int(m["num_reveals"]) == (((_np(rec["t"]) + 1) % 5) == 0).sum() > 0
+    assert 0.0 < float(m["mean_belief_ce"]) < np.log(env.N) + 1e-3 and float(m["mean_belief_ce_all_steps"]) > 0.0
     assert int(m["mrx_wins"]) + int(m["police_wins"]) == done.sum()
     assert 0.0 <= float(m["win_rate"]) <= 1.0 and float(m["mean_episode_length"]) >= 1.0
     # at reveal steps the belief is a delta on MrX: cross-entropy ~ 0 there
@@ -422,6 +480,25 @@ def test_rollout_metrics_on_device(sy):
     reveal = (t > 0) & (t % 5 == 0)
     assert reveal.any() and np.abs(ce[reveal]).max() < 1e-5
     env.close()
+    # the same reductions on the GPU against the goldens of the unmodified eval/metrics.py
+    # (tests/golden/metrics_reference.json, oracle/capture_metrics.py) — not only in the CPU suite
+    from tests.helpers import metrics_golden_record
+    with open(os.path.join(GOLDEN, "metrics_reference.json")) as f:
+        g = json.load(f)
+    grec = metrics_golden_record(g, device="cuda")
+    gm = M.rollout_metrics(grec, int(g["num_nodes"]), reveal_interval=int(g["reveal_interval"]))
+    a = g["aggregated"]
+    assert gm["win_rate"].is_cuda
+    for k in ("num_episodes", "mrx_wins", "police_wins"):
+        assert int(gm[k]) == int(a[k]), k
+    for k in ("win_rate", "mean_episode_length", "mean_time_to_catch", "mean_survival_time"):
+        assert abs(float(gm[k]) - a[k]) < 1e-4 * max(1.0, abs(a[k])), k
+    assert abs(float(gm["mean_belief_ce"]) - a["mean_belief_ce"]) < 1e-9
+    assert abs(float(gm["belief_ce_std"]) - a["belief_ce_std"]) < 1e-9
+    for c in g["ce_cases"]:
+        got = M.belief_cross_entropy(torch.tensor(c["belief"], dtype=torch.float64, device="cuda"),
+                                     torch.tensor(c["true_index"], device="cuda"))
+        assert abs(float(got) - c["ce"]) < 1e-10
 
 
 def test_device_board_sampler_statistics_and_use(sy, ol):
@@ -459,6 +536,19 @@ def test_device_board_sampler_statistics_and_use(sy, ol):
     assert np.abs(hd - hh).max() < 0.02, (hd, hh)       # same degree distribution (sampling error ~0.005)
     assert abs(np.mean([d.max() for d in dev_deg]) - np.mean([d.max() for d in host_deg])) < 1.0
     assert len({b.edge_links.tobytes() for b in pk.boards}) == G      # boards differ
+    # ... and both samplers against what the UNMODIFIED reference sampler realises (tests/golden/sampler_stats.json,
+    # oracle/capture_sampler_stats.py): degree / tree-degree / max-degree / weight histograms, realised edge counts
+    from student_mechanism_design_amd.graph import sample_boards_device_raw
+    from tests.helpers import assert_sampler_stats_close, sampler_stats
+    with open(os.path.join(GOLDEN, "sampler_stats.json")) as f:
+        gold = json.load(f)
+    for c in gold["configs"]:
+        n, e = c["nodes"], c["edges_requested"]
+        links, w, cnt = sample_boards_device_raw(min(c["boards"], 512), n, e, seed=900 + n)
+        ok = cnt >= 0
+        assert ok.mean() > 0.99                                        # a row wider than the ELL is a ~never event
+        got = sampler_stats(n, [links[i, : cnt[i]] for i in np.nonzero(ok)[0]], [w[i, : cnt[i]] for i in np.nonzero(ok)[0]])
+        assert_sampler_stats_close(c, got, what=f"device sampler N={n} E={e}")
     # unreachable edge counts: every board is redrawn to the first board's realised count
     sat = sy.sample_board_pool_device(6, 30, 70, seed=2)
     assert sat.num_edges < 70 and len(sat) == 6

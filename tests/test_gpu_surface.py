@@ -1,11 +1,13 @@
 """GPU tests of the reference-shaped surfaces: the B=1 PettingZoo-style facade (golden replay through
 `reset/step/get_possible_moves`) and the policy-driven collector."""
+import os
+
 import numpy as np
 import pytest
 
 torch = pytest.importorskip("torch")
 
-from tests.helpers import NONE_ACTION, load_trace, trace_index  # noqa: E402
+from tests.helpers import GOLDEN, NONE_ACTION, ROOT, load_trace, trace_index  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -555,3 +557,206 @@ def test_in_kernel_policy_other_shapes(sy, N, P, H, B):
     np.testing.assert_allclose(_np(rec["log_prob"])[_np(~empty)], _np(want)[_np(~empty)], rtol=0, atol=2e-3)
     env.close()
     twin.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# returns / advantages / GAE as one HIP kernel (sy_returns_advantages)
+# ----------------------------------------------------------------------------------------------
+def test_device_returns_match_the_unmodified_ppo_update(sy):
+    """tests/golden/ppo_returns_reference.npz (captured from MappoAgent.ppo_update, mappo_agent.py:247-258):
+    the float32 kernel reproduces the reference's returns bit for bit, advantages after the torch standardisation."""
+    from student_mechanism_design_amd import collector as col
+    z = np.load(os.path.join(GOLDEN, "ppo_returns_reference.npz"))
+    dev = torch.device("cuda")
+    for name in z["case_names"]:
+        rew = torch.tensor(z[f"{name}/reward"], device=dev).reshape(-1, 1, 1)             # float64, like the record's
+        done = torch.tensor(z[f"{name}/done"], device=dev).reshape(-1, 1)
+        val = torch.tensor(z[f"{name}/values"], device=dev).reshape(-1, 1)
+        ret, adv = col.device_returns(rew, done, float(z[f"{name}/gamma"]), values=val)
+        np.testing.assert_array_equal(_np(ret).reshape(-1), z[f"{name}/returns"], err_msg=name)
+        a = col.standardized_advantages(ret.reshape(-1), val.reshape(-1))
+        np.testing.assert_allclose(_np(a), z[f"{name}/advantages"], rtol=1e-6, atol=1e-6, err_msg=name)
+        np.testing.assert_array_equal(_np(adv).reshape(-1), z[f"{name}/returns"] - z[f"{name}/values"], err_msg=name)
+
+
+def test_device_returns_on_a_rollout_record_in_place(sy):
+    """The kernel reads the packed record where it lies (strided float64 rewards, int32 flags) for all (env, agent)
+    columns at once; checked against the oracle's restatement (float32 bit-exact, float64 GAE to 1e-12), the
+    lambda = 1 reduction, and the plain-torch loops it replaces."""
+    from oracle import oracle_lib as ol
+    from student_mechanism_design_amd import collector as col
+    boards = sy.sample_board_pool(2, 60, 100, seed=4)
+    env = sy.BatchedScotlandYardEnv(300, boards, 4, 12, np.linspace(0.1, 0.9, 11), seed=9, reveal_interval=5)
+    T = 70
+    rec = env.rollout(T)
+    done_np = (_np(rec["terminated"]) | _np(rec["truncated"])).astype(np.uint8)
+    rew_np = _np(rec["reward"])
+    assert done_np.any()
+    gamma = 0.97
+    # mode 0, float32: bit-exact vs the C restatement of mappo_agent.py:247-258
+    gen = torch.Generator(device="cpu").manual_seed(3)
+    val_c = torch.randn(T, env.B, generator=gen).to(env.device)                              # central critic [T, B]
+    ret, adv = col.device_returns(rec["reward"], rec["terminated"], gamma, done_b=rec["truncated"], values=val_c)
+    want_ret, want_adv = ol.discounted_returns_f32(rew_np.astype(np.float32), done_np, gamma,
+                                                   _np(val_c)[..., None].repeat(env.A, -1))
+    np.testing.assert_array_equal(_np(ret), want_ret)
+    np.testing.assert_array_equal(_np(adv), want_adv)
+    # ... and the torch loop it replaces (same maths, different rounding order)
+    loop = col.discounted_returns(rec["reward"].float(), torch.as_tensor(done_np, device=env.device), gamma)
+    np.testing.assert_allclose(_np(ret), _np(loop), rtol=1e-5, atol=1e-5)
+    # float64 keeps the engine's float64 rewards
+    ret64, _ = col.device_returns(rec["reward"], rec["terminated"], gamma, done_b=rec["truncated"], dtype=torch.float64)
+    run, want64 = np.zeros_like(rew_np[0]), np.zeros_like(rew_np)
+    for t in range(T - 1, -1, -1):
+        run = rew_np[t] + (gamma * run) * (1.0 - done_np[t][:, None])
+        want64[t] = run
+    np.testing.assert_array_equal(_np(ret64), want64)
+    # GAE float64 vs the oracle, per-agent values and a bootstrap
+    val_a = torch.randn(T, env.B, env.A, generator=gen).to(env.device)
+    last = torch.randn(env.B, env.A, generator=gen).to(env.device)
+    g_ret, g_adv = col.device_returns(rec["reward"], rec["terminated"], gamma, done_b=rec["truncated"], values=val_a,
+                                      lam=0.9, last_value=last, dtype=torch.float64)
+    o_adv, o_ret = ol.gae_f64(rew_np, done_np, _np(val_a).astype(np.float64), gamma, 0.9, _np(last).astype(np.float64))
+    np.testing.assert_allclose(_np(g_adv), o_adv, rtol=0, atol=1e-12)
+    np.testing.assert_allclose(_np(g_ret), o_ret, rtol=0, atol=1e-12)
+    t_adv, t_ret = col.gae(rec["reward"], val_a.double(), torch.as_tensor(done_np, device=env.device), last.double(), gamma, 0.9)
+    np.testing.assert_allclose(_np(g_adv), _np(t_adv), rtol=0, atol=1e-9)
+    # lambda = 1, zero bootstrap: GAE's returns are the reference's returns (SURVEY 8a-13's parity check)
+    l1_ret, _ = col.device_returns(rec["reward"], rec["terminated"], gamma, done_b=rec["truncated"], values=val_a, lam=1.0,
+                                   dtype=torch.float64)
+    np.testing.assert_allclose(_np(l1_ret), want64, rtol=0, atol=1e-9)
+    # uint8 / bool flags are accepted as well
+    ret_u8, _ = col.device_returns(rec["reward"], torch.as_tensor(done_np, device=env.device).bool(), gamma, values=val_c)
+    np.testing.assert_array_equal(_np(ret_u8), want_ret)
+    with pytest.raises(sy.EngineError):
+        col.device_returns(rec["reward"].cpu(), rec["terminated"].cpu(), gamma)
+    env.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# failures are reported, not swallowed (sy_env_status)
+# ----------------------------------------------------------------------------------------------
+_FAULT_SCRIPT = r"""
+import sys, numpy as np, torch
+import student_mechanism_design_amd as sy
+boards = sy.sample_board_pool(1, 40, 70, seed=1)
+env = sy.BatchedScotlandYardEnv(64, boards, 3, 10, np.full(11, 0.5), seed=2, reveal_interval=5)
+assert env.status() == 0
+env.rollout(8)
+w8 = env.status()
+raised = False
+try:
+    env.check_status()
+except sy.EngineError as e:
+    raised = "belief wave gave up" in str(e)
+after_clear = env.status()
+env.rollout(24)
+w24 = env.status()
+print("RESULT", w8, int(raised), after_clear, w24)
+"""
+
+
+def test_status_word_reports_a_lost_handoff(sy):
+    """VERDICT r1 #8.  libsy_env_fault.so is the engine compiled with -DSY_INJECT_LOST_HANDOFF -DSY_SPIN_MAX=2048:
+    episode 0's move wave stops publishing its ring entries after step 2.  The launch must still drain, and the
+    status word must say what happened: the belief wave's bounded wait expires (bit 1) and, on a longer launch, the
+    move wave's back-pressure wait too (bit 2).  The shipped library on the same workload reports nothing."""
+    import subprocess
+    import sys
+    from student_mechanism_design_amd import build as B
+    if not os.path.exists(B.FAULT_LIB):
+        pytest.fail("libsy_env_fault.so missing: run __graft_entry__.build() (it compiles the fault-injection variant)")
+    env_vars = dict(os.environ, SY_ENGINE_LIB=B.FAULT_LIB, PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", _FAULT_SCRIPT], env=env_vars, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    w8, raised, after_clear, w24 = (int(x) for x in out.stdout.strip().splitlines()[-1].split()[1:])
+    assert w8 & sy._lib.STATUS_BELIEF_WAIT_EXPIRED and raised == 1 and after_clear == 0
+    assert w24 & sy._lib.STATUS_BELIEF_WAIT_EXPIRED and w24 & sy._lib.STATUS_RING_WAIT_EXPIRED
+    # the product library: clean
+    boards = sy.sample_board_pool(1, 40, 70, seed=1)
+    env = sy.BatchedScotlandYardEnv(64, boards, 3, 10, np.full(11, 0.5), seed=2, reveal_interval=5)
+    env.rollout(24)
+    assert env.status() == 0
+    env.check_status()
+    env.close()
+
+
+# ----------------------------------------------------------------------------------------------
+# reset epochs (ADVICE r1): a seedless reset starts NEW episodes, an explicit seed reproduces
+# ----------------------------------------------------------------------------------------------
+def test_seedless_resets_give_new_episodes(sy):
+    from oracle import oracle_lib as ol
+    boards = sy.sample_board_pool(1, 50, 90, seed=2)
+    w = np.full(11, 0.5)
+    env = sy.BatchedScotlandYardEnv(128, boards, 3, 10, w, seed=5)
+    first = _np(env.pos).copy()
+    acts0 = _np(env.rollout(6)["action"]).copy()
+    env.reset()
+    second = _np(env.pos).copy()
+    acts1 = _np(env.rollout(6)["action"]).copy()
+    env.reset()
+    third = _np(env.pos).copy()
+    assert env.reset_epoch == 2
+    assert not np.array_equal(first, second) and not np.array_equal(second, third) and not np.array_equal(first, third)
+    assert not np.array_equal(acts0, acts1)
+    # what runs after a seedless reset is still the oracle's stream for `stream_key`
+    graphs = [ol.OracleGraph(50, boards[0].edge_links, boards[0].edges.astype(np.int32))]
+    orc = ol.OracleBatch(graphs, env.env_graph_host, 128, 3, 10, node_stride=env.NS, weights=w, tables=sy.reward_tables())
+    orc.reset(seed=env.stream_key)
+    np.testing.assert_array_equal(third, orc.pos)
+    np.testing.assert_array_equal(_np(env.rollout(10)["action"]), orc.rollout(10)["action"])
+    # an explicit seed restarts the streams: same episodes as a fresh env with that seed
+    env.reset(seed=5)
+    assert env.reset_epoch == 0
+    np.testing.assert_array_equal(_np(env.pos), first)
+    np.testing.assert_array_equal(_np(env.rollout(6)["action"]), acts0)
+    # a masked reset leaves the other envs and the key alone; a new seed with a mask is refused
+    before = _np(env.pos).copy()
+    sel = torch.zeros(128, dtype=torch.bool, device=env.device)
+    sel[::4] = True
+    env.reset(env_mask=sel)
+    after = _np(env.pos)
+    np.testing.assert_array_equal(after[~_np(sel)], before[~_np(sel)])
+    assert env.reset_epoch == 0
+    with pytest.raises(ValueError):
+        env.reset(seed=9, env_mask=sel)
+    env.close()
+    # the B = 1 facade: reset() without an episode index must not replay the same episode (reference callers such
+    # as eval/ood_eval.py:211 call reset(**kwargs) with no episode)
+    from student_mechanism_design_amd.pettingzoo_api import CustomEnvironment
+    fac = CustomEnvironment(2, 10, {k: 0.5 for k in sy.REWARD_WEIGHT_NAMES}, graph_nodes=30, graph_edges=50, seed=1)
+    starts = set()
+    for _ in range(6):
+        fac.reset(options={"board": fac.board})
+        starts.add((fac.MrX_pos[0],) + tuple(fac.police_positions))
+    assert len(starts) >= 4
+    fac.close()
+
+
+def test_belief_tracker_reads_adjacency_rows_as_given(sy):
+    """`ParticleBeliefTracker.update` moves a particle on node i to a uniform element of
+    nonzero(adjacency[i]) (belief_module.py:88-96) — directed rows stay directed and a non-zero diagonal is a
+    self-neighbour.  Expected values: the forward filter b' = normalize((b P) * lik) written out in numpy here."""
+    rng = np.random.default_rng(5)
+    n = 12
+    adj = (rng.random((n, n)) < 0.25).astype(float)                  # directed, with some self loops
+    np.fill_diagonal(adj, (rng.random(n) < 0.5).astype(float))
+    adj[3, :] = 0                                                    # an isolated row: its mass stays put
+    tr = sy.DeviceBeliefTracker(n, adj, num_beliefs=2)
+    b = np.full(n, 1.0 / n)
+    for step in range(5):
+        hint = [int(x) for x in rng.choice(n, size=2, replace=False)] if step % 2 else None
+        deg = (adj != 0).sum(1)
+        P = np.where(deg[:, None] > 0, (adj != 0) / np.maximum(deg, 1)[:, None], np.eye(n))
+        nb = b @ P
+        if hint is not None:
+            lik = np.full(n, 0.1)
+            lik[hint] = 1.0
+            nb = nb * lik
+        b = nb / nb.sum()
+        got = _np(tr.update(adj, observation_hint=hint))
+        np.testing.assert_allclose(got[0], b, atol=1e-6)
+        np.testing.assert_allclose(got[1], b, atol=1e-6)
+    wide = np.ones((20, 20))
+    with pytest.raises(ValueError):
+        sy.DeviceBeliefTracker(20, wide)                             # 20 in-neighbours > ELL width

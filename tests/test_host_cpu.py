@@ -138,6 +138,103 @@ def test_capi_argument_validation_without_gpu():
     assert lib.sy_belief_update(None, None, 3, 16, None, None, 0, None, 1, None) == -1
 
 
+def test_capi_rejects_batches_whose_rows_overflow_32_bit_cursors():
+    """Kernel cursors are 32-bit byte offsets: B * NS * 4 (one belief row of the batch) must stay below 4 GiB."""
+    lib = sy._lib.load()
+    h = C.c_void_p()
+    too_big = sy._lib.EnvConfig(1 << 21, 1024, 2, 10, 250, 1, 1024, 0, 0, 0, 1, 0, 0)   # 2 Mi envs x 1024 nodes x 4 B = 8 GiB
+    assert lib.sy_env_create(C.byref(too_big), C.byref(h)) == -1
+    assert b"4 GiB" in lib.sy_last_error()
+    assert lib.sy_env_bind_status(None, None) == -1
+    args = sy._lib.ReturnsArgs()
+    assert lib.sy_returns_advantages(C.byref(args), None) == -1       # null pointers are refused, nothing launches
+
+
+def test_rollout_buffer_validation_fires_before_the_abi_sees_a_pointer():
+    """a record from alloc_rollout(T') with T' < T must not reach the kernel (it would write past it)."""
+    import types
+    import torch
+    from student_mechanism_design_amd.env import BatchedScotlandYardEnv, make_rollout_record, record_words
+    B, A, NS = 6, 3, 16
+    fake = types.SimpleNamespace(B=B, A=A, NS=NS, lib=sy._lib.load(), device=torch.device("cpu"), _belief=object())
+    check = BatchedScotlandYardEnv._check_rollout_buffers
+    good = make_rollout_record(8, B, A, NS, record_words(A), "cpu", log_prob=True)
+    check(fake, good, 8)
+    check(fake, good, 8, need_log_prob=True)
+    with pytest.raises(ValueError, match="shape"):
+        check(fake, good, 9)                                            # too few rows
+    with pytest.raises(ValueError, match="log_prob"):
+        check(fake, make_rollout_record(8, B, A, NS, record_words(A), "cpu"), 8, need_log_prob=True)
+    bad = dict(good)
+    bad["mask"] = good["mask"][:, :, :, : NS - 1]
+    with pytest.raises(ValueError, match="mask"):
+        check(fake, bad, 8)                                             # wrong trailing shape
+    bad = dict(good)
+    bad["belief"] = good["belief"].double()
+    with pytest.raises(ValueError, match="belief"):
+        check(fake, bad, 8)                                             # wrong dtype
+    bad = dict(good)
+    bad["record"] = torch.zeros((8, B, 2 * record_words(A)), dtype=torch.int32)[:, :, ::2]
+    with pytest.raises(ValueError, match="contiguous"):
+        check(fake, bad, 8)
+    bad = dict(good)
+    bad["record"] = None
+    with pytest.raises(ValueError, match="record"):
+        check(fake, bad, 8)
+    fake_other = types.SimpleNamespace(B=B, A=A, NS=NS, lib=fake.lib, device=torch.device("cuda", 0), _belief=object())
+    with pytest.raises(ValueError, match="lives on"):
+        check(fake_other, good, 8)                                      # wrong device
+    fake_nobelief = types.SimpleNamespace(B=B, A=A, NS=NS, lib=fake.lib, device=torch.device("cpu"), _belief=None)
+    with pytest.raises(ValueError, match="no belief"):
+        check(fake_nobelief, good, 8)
+
+
+def test_reset_epoch_key_schedule():
+    from student_mechanism_design_amd.env import _splitmix64
+    keys = {_splitmix64((7 + 0xD1B54A32D192ED03 * e) & (2**64 - 1)) for e in range(1, 200)}
+    assert len(keys) == 199 and 7 not in keys                       # distinct keys per epoch, none equal to the seed
+    assert _splitmix64(0) == 0xE220A8397B1DCDAF                      # SplitMix64 known answer (first output for state 0)
+
+
+def test_sample_board_redraws_boards_wider_than_the_ell():
+    """pack_ell raises above 16 neighbours but the sampler never redrew such a board."""
+    from student_mechanism_design_amd import graph as G
+    calls = {"n": 0}
+    real = G._sample_board_once
+
+    def star_first(n, e, cap, rng):
+        calls["n"] += 1
+        if calls["n"] == 1:         # a 20-leaf star: degree 20 > 16
+            return G.make_board(21, np.array([(0, i) for i in range(1, 21)], dtype=np.int32), np.ones(20, dtype=np.int64))
+        return real(n, e, cap, rng)
+
+    G._sample_board_once = star_first
+    try:
+        b = G.sample_board(21, 30, rng=np.random.default_rng(0))
+    finally:
+        G._sample_board_once = real
+    assert calls["n"] == 2 and G.max_degree(b) <= 16
+    G.pack_ell(b)
+
+
+def test_host_board_sampler_matches_the_reference_sampler_statistics():
+    """VERDICT r1 #7.  tests/golden/sampler_stats.json holds what the UNMODIFIED ConnectedGraph.sample
+    (graph_layout.py:9-80) realises for (15, 20), (50, 110), (100, 190), (200, 400): degree / tree-degree / max-degree /
+    weight histograms and realised edge counts (at (50, 110) the degree cap stops the sampler at 99-105 edges).  The
+    host sampler draws from its own Generator, so it is held to them within sampling error."""
+    import json
+    from tests.helpers import GOLDEN, assert_sampler_stats_close, sampler_stats
+    with open(os.path.join(GOLDEN, "sampler_stats.json")) as f:
+        g = json.load(f)
+    assert [(c["nodes"], c["edges_requested"]) for c in g["configs"]] == [(15, 20), (50, 110), (100, 190), (200, 400)]
+    for c in g["configs"]:
+        n, e = c["nodes"], c["edges_requested"]
+        rng = np.random.default_rng(77 + n)
+        boards = [sy.sample_board(n, e, rng=rng) for _ in range(min(c["boards"], 300))]
+        got = sampler_stats(n, [b.edge_links for b in boards], [b.edges for b in boards])
+        assert_sampler_stats_close(c, got, what=f"host sampler N={n} E={e}")
+
+
 def test_product_path_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

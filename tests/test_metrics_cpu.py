@@ -56,21 +56,15 @@ def test_metrics_match_the_reference_goldens():
     for c in g["ce_cases"]:
         got = M.belief_cross_entropy(torch.tensor(c["belief"], dtype=torch.float64), torch.tensor(c["true_index"]))
         assert abs(float(got) - c["ce"]) < 1e-10
-    eps = g["episodes"]
-    T, B, A = max(e["length"] for e in eps), len(eps), 3
-    rec = {
-        "terminated": torch.zeros(T, B, dtype=torch.int32), "truncated": torch.zeros(T, B, dtype=torch.int32),
-        "winner": torch.zeros(T, B, dtype=torch.int32), "t": torch.arange(T).unsqueeze(1).expand(T, B).clone().int(),
-        "budget": torch.full((T, B, A), 5, dtype=torch.int32), "pos": torch.zeros(T, B, A, dtype=torch.int32),
-    }
-    for b, e in enumerate(eps):
-        s = e["length"] - 1
-        rec["terminated"][s, b] = 1
-        rec["winner"][s, b] = 1 if e["winner"] == "Police" else 2
-        rec["t"][s + 1:, b] = 0           # (rows after the end belong to the next episode; they finish nothing)
-    m = M.rollout_metrics(rec, 10)
+    from tests.helpers import metrics_golden_record
+    rec = metrics_golden_record(g)
+    m = M.rollout_metrics(rec, int(g["num_nodes"]), reveal_interval=int(g["reveal_interval"]))
     a = g["aggregated"]
     assert int(m["num_episodes"]) == int(a["num_episodes"]) and int(m["mrx_wins"]) == int(a["mrx_wins"])
     assert int(m["police_wins"]) == int(a["police_wins"])
+    assert int(m["num_reveals"]) == sum(len(e["reveals"]) for e in g["episodes"]) > 0
     for k in ("win_rate", "mean_episode_length", "mean_time_to_catch", "mean_survival_time"):
         assert abs(float(m[k]) - a[k]) < 1e-4 * max(1.0, abs(a[k])), k
+    # belief quality at reveal times (eval/metrics.py:138-141,198-199)
+    assert abs(float(m["mean_belief_ce"]) - a["mean_belief_ce"]) < 1e-9
+    assert abs(float(m["belief_ce_std"]) - a["belief_ce_std"]) < 1e-9

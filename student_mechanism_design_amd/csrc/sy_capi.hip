@@ -73,7 +73,7 @@ int sy_env_create(const sy_env_config* c, sy_env** out) {
     p.auto_reset = c->auto_reset ? 1 : 0;
     p.env_id_offset = c->env_id_offset;
     // per-episode LDS slice: mask rows, visit counters, belief scratch, hand-off ring, sync words
-    p.wave_lds_bytes = p.A * p.NS + p.NS * 4 + (p.NS + 16) * 8 + SY_RING * 32 + 16 + 256;
+    p.wave_lds_bytes = p.A * p.NS + p.NS * 4 + (p.NS + 16) * 8 + SY_RING * SY_RING_ENTRY_BYTES + 16 + 256;
     p.rec_words = sy_record_words(p.A);
     p.scan_w = 16;
     // per-block LDS: board ELL (64 B/node) + belief gather offsets (32 B/node) + reward tables

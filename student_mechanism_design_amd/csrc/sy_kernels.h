@@ -7,7 +7,9 @@
 
 #define SY_LDS_TABLE 256   // exp(-d) / coverage / -1/(d+1) entries staged in LDS per launch block
 #define SY_LDS_AVGTAB 512  // -1/(sum/P+1) entries staged in LDS per launch block
-#define SY_RING 16         // move wave -> belief wave ring depth (steps)
+#define SY_RING 16         // move wave -> helper / belief wave ring depth (steps)
+#define SY_RING_ENTRY_BYTES 64   // ring bytes per episode = SY_RING x this: 16 entries of 32 B (used) for the two older rollout
+                                 // kernels, 8 entries of 128 B (8 agent slots x 16 B) for the rollout3 pipeline
 
 namespace sy {
 

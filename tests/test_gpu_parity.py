@@ -229,7 +229,9 @@ def test_rollout_equals_stepping_its_own_actions(sy):
     for s in range(50):
         np.testing.assert_array_equal(_np(b.pos), _np(rec["pos"][s]))
         np.testing.assert_array_equal(_np(b._mask), _np(rec["mask"][s]))
-        np.testing.assert_array_equal(_np(b._belief), _np(rec["belief"][s]))
+        # (the fused rollout renormalises the belief every few steps, the step kernel on every step: equal up to
+        # float32 rounding, both within 1e-5 of the oracle)
+        np.testing.assert_allclose(_np(b._belief), _np(rec["belief"][s]), rtol=0, atol=2e-6)
         b.step(rec["action"][s].contiguous())
         np.testing.assert_array_equal(_np(b.reward), _np(rec["reward"][s]))
         np.testing.assert_array_equal(_np(b._terminated), _np(rec["terminated"][s]))
@@ -283,8 +285,10 @@ def test_full_size_properties(sy):
         env2.rollout(1, record=False)
     env3 = sy.BatchedScotlandYardEnv(B, boards, P, 20, np.full(11, 0.5), seed=3, reveal_interval=5)
     env3.rollout(8, record=False)
-    for name in ("pos", "budget", "t", "_mask", "_belief", "_visits", "reward"):
+    for name in ("pos", "budget", "t", "_mask", "_visits", "reward"):
         assert torch.equal(getattr(env2, name), getattr(env3, name)), name
+    # the belief is renormalised when a launch ends and every 8th step inside one: equal up to float32 rounding
+    assert torch.allclose(env2._belief, env3._belief, rtol=0, atol=2e-6)
     # different seeds / env_id_offset give different streams
     env4 = sy.BatchedScotlandYardEnv(B, boards, P, 20, np.full(11, 0.5), seed=3, env_id_offset=B)
     env5 = sy.BatchedScotlandYardEnv(B, boards, P, 20, np.full(11, 0.5), seed=3)

@@ -114,8 +114,10 @@ def test_policy_driven_collector_matches_fused_rollout(sy):
         return script[s], torch.zeros_like(script[s], dtype=torch.float32), torch.zeros(96, device=script.device)
 
     got = col.RolloutCollector(b, replay_policy, frames_per_batch=40).collect()
-    for k in ("pos", "budget", "t", "action", "mask", "belief", "reward", "terminated", "truncated", "winner"):
+    for k in ("pos", "budget", "t", "action", "mask", "reward", "terminated", "truncated", "winner"):
         assert torch.equal(got[k], fused[k]), k
+    # (the fused rollout renormalises the belief every few steps, the step kernel on every step: float32 rounding)
+    assert torch.allclose(got["belief"], fused["belief"], rtol=0, atol=2e-6)
     assert got["log_prob"].shape == (40, 96, 4) and got["value"].shape == (40, 96)
 
     # a masked-softmax policy only ever emits legal moves

@@ -359,12 +359,32 @@ static void init_episode(const syo_batch_config *c, const syo_graph *g, syo_batc
 }
 
 static void sample_starts(const syo_batch_config *c, int32_t e, uint32_t ctr, uint64_t seed, int32_t *starts) {
-    /* distinct start nodes, uniform without replacement (yard.py:112-116; own RNG stream) */
-    const int32_t A = c->P + 1;
+    /* distinct start nodes, uniform over ordered tuples of distinct nodes (yard.py:112-116
+     * np.random.choice(N, A, replace=False); own RNG stream, engine-defined):
+     *   boards with N >= 2 A^2 (collisions are rare): REJECTION of whole tuples — attempt j = 0, 1, ... takes word
+     *   (j & 3) of Philox block (env, ctr, RESET << 8 | (j >> 2) << 3 | agent), node = mulhi(word, N), and the first
+     *   attempt whose nodes are pairwise distinct wins (same distribution as drawing without replacement);
+     *   smaller boards, or 128 failed attempts (probability < 4^-128): sequential draws without replacement from
+     *   word 0 of block (env, ctr, RESET << 8 | agent). */
+    const int32_t A = c->P + 1, N = c->N;
+    const uint64_t gid = c->env_id_offset + (uint64_t)e;
+    if (N >= 2 * A * A) {
+        for (uint32_t j = 0; j < 128; ++j) {
+            int ok = 1;
+            for (int32_t i = 0; i < A; ++i) {
+                uint32_t o[4];
+                syo_philox4x32((uint32_t)gid, (uint32_t)(gid >> 32), ctr, (PURPOSE_RESET << 8) | ((j >> 2) << 3) | (uint32_t)i,
+                               (uint32_t)seed, (uint32_t)(seed >> 32), o);
+                starts[i] = (int32_t)mulhi32(o[j & 3u], (uint32_t)N);
+                for (int32_t k = 0; k < i; ++k) ok = ok && starts[k] != starts[i];
+            }
+            if (ok) return;
+        }
+    }
     int32_t sorted[SYO_MAX_AGENTS];
     for (int32_t i = 0; i < A; ++i) {
-        uint32_t x = draw(c->env_id_offset + (uint64_t)e, ctr, PURPOSE_RESET, (uint32_t)i, seed);
-        int32_t r = (int32_t)mulhi32(x, (uint32_t)(c->N - i));
+        uint32_t x = draw(gid, ctr, PURPOSE_RESET, (uint32_t)i, seed);
+        int32_t r = (int32_t)mulhi32(x, (uint32_t)(N - i));
         int32_t n = i;
         for (int32_t j = 0; j < n; ++j)
             if (r >= sorted[j]) ++r;

@@ -124,11 +124,43 @@ __device__ __forceinline__ void philox4(uint64_t gid, uint32_t ctr, uint32_t pur
     o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
 
-// Distinct start nodes, uniform without replacement (replaces np.random.choice(N, A, replace=False),
-// yard.py:112-116): draw i = word 0 of philox(env, step_count, RESET, i).  All values are
-// wave-uniform; lane a returns agent a's start.
+// lane i <- lane i - D inside its row of 16 (agents of an episode sit on lanes 0..7 of a row); zero fill
+template <int D>
+__device__ __forceinline__ int dpp_row_shr(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, 0x110 + D, 0xf, 0xf, true);
+}
+// lanes whose value equals the value of an earlier agent lane of the same row (lanes a with d <= a < A, any d)
+__device__ __forceinline__ uint64_t earlier_duplicates(int r, int A) {
+    uint64_t dup = 0;
+    const uint64_t rows = 0x0001000100010001ull;          // lane 0 of every row of 16
+    const uint64_t agents = ((1ull << A) - 1ull) * rows;
+    dup |= __builtin_amdgcn_ballot_w64(r == dpp_row_shr<1>(r)) & agents & ~(((1ull << 1) - 1ull) * rows);
+    if (A > 2) dup |= __builtin_amdgcn_ballot_w64(r == dpp_row_shr<2>(r)) & agents & ~(((1ull << 2) - 1ull) * rows);
+    if (A > 3) dup |= __builtin_amdgcn_ballot_w64(r == dpp_row_shr<3>(r)) & agents & ~(((1ull << 3) - 1ull) * rows);
+    if (A > 4) dup |= __builtin_amdgcn_ballot_w64(r == dpp_row_shr<4>(r)) & agents & ~(((1ull << 4) - 1ull) * rows);
+    if (A > 5) dup |= __builtin_amdgcn_ballot_w64(r == dpp_row_shr<5>(r)) & agents & ~(((1ull << 5) - 1ull) * rows);
+    if (A > 6) dup |= __builtin_amdgcn_ballot_w64(r == dpp_row_shr<6>(r)) & agents & ~(((1ull << 6) - 1ull) * rows);
+    if (A > 7) dup |= __builtin_amdgcn_ballot_w64(r == dpp_row_shr<7>(r)) & agents & ~(((1ull << 7) - 1ull) * rows);
+    return dup;
+}
+
+// Distinct start nodes, uniform over ordered tuples of distinct nodes (replaces np.random.choice(N, A,
+// replace=False), yard.py:112-116; own RNG stream, engine-defined).  Boards with N >= 2 A^2 (collisions are rare):
+// REJECTION of whole tuples — attempt j = 0, 1, ... takes word (j & 3) of Philox block (env, ctr, RESET << 8 |
+// (j >> 2) << 3 | agent), node = mulhi(word, N); the first attempt whose nodes are pairwise distinct wins (the same
+// distribution as drawing without replacement, ~A^2 / 2N retries).  Smaller boards, or 128 failed attempts: sequential
+// draws without replacement from word 0 of block (env, ctr, RESET << 8 | agent).  Lane a returns agent a's start.
 __device__ __noinline__ int sample_starts(int lane, int A, int N, uint64_t gid, uint32_t ctr, uint32_t k0, uint32_t k1) {
     uint32_t o[4];
+    if (N >= 2 * A * A) {
+        for (uint32_t j = 0; j < 128u; ++j) {
+            if ((j & 3u) == 0u) philox4(gid, ctr, kPurposeReset, ((j >> 2) << 3) | ((uint32_t)lane & 7u), k0, k1, o);
+            const uint32_t m = j & 3u;
+            const uint32_t x = m == 0 ? o[0] : (m == 1 ? o[1] : (m == 2 ? o[2] : o[3]));
+            const int r = (int)__umulhi(x, (uint32_t)N);
+            if ((earlier_duplicates(r, A) & 0xffull) == 0ull) return r;
+        }
+    }
     philox4(gid, ctr, kPurposeReset, (uint32_t)lane, k0, k1, o);
     const uint32_t xv = o[0];
     int sorted[SY_MAX_AGENTS];
@@ -1605,16 +1637,30 @@ __device__ __forceinline__ bool hany(bool pred, bool upper) {               // p
     return (upper ? (uint32_t)(bm >> 32) : (uint32_t)bm) != 0u;
 }
 
-// sample_starts (distinct start nodes, see above) for the halves named in `need` (bit 0 / bit 32):
-// values are replicated per half instead of wave-uniform; the draws are vector work (one Philox
-// block per agent lane), the without-replacement bookkeeping runs on the scalar unit — its values
-// are uniform per half — and the results are dropped onto the agent lanes one by one.
+// sample_starts (distinct start nodes, see above) for the halves named in `need` (bit 0 / bit 32): agent a of half h
+// sits on lane 32 h + a; gid / ctr are replicated per half.  Tuple rejection: one Philox block per agent lane serves
+// four attempts, distinctness is four DPP row shifts and scalar masks; the sequential fallback (small boards) draws on
+// the vector unit and keeps the without-replacement bookkeeping on the scalar unit — its values are uniform per half.
 __device__ __forceinline__ int sample_starts_pair(uint64_t need, int ln, int a, int A, int N, uint64_t gid, uint32_t ctr,
                                                uint32_t k0, uint32_t k1) {
     uint32_t o[4];
+    int st = 0;
+    if (N >= 2 * A * A) {
+        uint64_t todo = half_any(need);
+        for (uint32_t j = 0; j < 128u && todo != 0ull; ++j) {
+            if ((j & 3u) == 0u) philox4(gid, ctr, kPurposeReset, ((j >> 2) << 3) | ((uint32_t)a & 7u), k0, k1, o);
+            const uint32_t m = j & 3u;
+            const uint32_t x = m == 0 ? o[0] : (m == 1 ? o[1] : (m == 2 ? o[2] : o[3]));
+            const int r = (int)__umulhi(x, (uint32_t)N);
+            const uint64_t good = todo & ~half_any(earlier_duplicates(r, A) & 0x000000ff000000ffull);
+            st = lanes(good) ? r : st;
+            todo &= ~good;
+        }
+        if (todo == 0ull) return st;
+        need = todo;
+    }
     philox4(gid, ctr, kPurposeReset, (uint32_t)a, k0, k1, o);
     const int xv = (int)o[0];
-    int st = 0;
     for (int h = 0; h < 2; ++h) {
         if (((need >> (32 * h)) & 1ull) == 0ull) continue;
         int sorted[SY_MAX_AGENTS];

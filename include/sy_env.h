@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SY_ABI_VERSION 3
+#define SY_ABI_VERSION 4
 #define SY_ELL_WIDTH 16
 #define SY_MAX_AGENTS 8
 #define SY_MAX_NODES 1024
@@ -115,6 +115,10 @@ typedef struct sy_mappo_weights {
     const float *w1t, *b1, *w2t, *b2, *c1t, *cb1, *c2, *cb2;
     const float *w2;   /* [A][N][H] second actor layers in torch's own layout (a node's row contiguous): needed by
                           sy_env_set_policy only, may be NULL for sy_mappo_policy_act */
+    const float *logit_bound; /* [A] an upper bound of every logit actor a can produce, over all observations:
+                          max_n (b2[n] + sum_k max(w2[n][k], 0) * hmax[k]), hmax[k] = max(b1[k], 0) + hot * max_n max(w1[k][n], 0)
+                          (hot = 1 for MrX's one-hot input, P for the police actors' multi-hot input).  Used by
+                          sy_env_set_policy's underflow rule; NULL = the rule is not applied */
 } sy_mappo_weights;
 
 /* dwords per record row for A = num_police + 1 agents: 5A+4 rounded up to a multiple of 4 */
@@ -170,9 +174,13 @@ int sy_env_rollout(sy_env *env, int32_t T, const sy_rollout_buffers *out, void *
  * after this call sy_env_rollout samples every action from the MAPPO actors instead of uniformly — inside the
  * fused kernel, per (env, agent): hidden = relu(b1 + row lookups of w1t), a logit per affordable neighbour
  * (w2 row . hidden + b2), action ~ softmax over the affordable neighbours (= the reference's masked, renormalised
- * softmax; its 1e-8 underflow fallback is not reproduced), log-probability into sy_rollout_buffers.log_prob.
- * w = NULL restores the uniform-random policy.  hidden: a multiple of 4, at most 64.  The weights must stay valid
- * and unchanged while launches are in flight. */
+ * softmax), log-probability into sy_rollout_buffers.log_prob.  The reference's underflow rule (mappo_agent.py:123-134:
+ * legal actions holding <= 1e-8 of the softmax mass -> uniform over the mask) is applied exactly when `logit_bound` is
+ * given: a cheap bound rules it out on almost every step, otherwise the actor's N logits are evaluated.  An agent
+ * without a legal action gets action -1 and log-probability 0 (the reference would draw an illegal node uniformly,
+ * which its env ignores: the agent stays either way).
+ * w = NULL restores the uniform-random policy.  hidden: a multiple of 4, at most 128 on boards of up to 256 nodes
+ * (the pipeline kernel), at most 64 otherwise.  The weights must stay valid and unchanged while launches are in flight. */
 int sy_env_set_policy(sy_env *env, const sy_mappo_weights *w, int32_t hidden);
 
 /* replaces compute_action_mask (action_mask.py:30-84), batched over Q queries on dense float64

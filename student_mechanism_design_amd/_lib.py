@@ -11,7 +11,7 @@ MAX_AGENTS = 8
 MAX_NODES = 1024
 NUM_WEIGHTS = 11
 MRX_MONEY = 1000
-ABI_VERSION = 3
+ABI_VERSION = 4
 STATUS_BELIEF_WAIT_EXPIRED = 1
 STATUS_RING_WAIT_EXPIRED = 2
 
@@ -34,7 +34,7 @@ class EnvState(C.Structure):
 
 
 class MappoWeights(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("w1t", "b1", "w2t", "b2", "c1t", "cb1", "c2", "cb2", "w2")]
+    _fields_ = [(n, C.c_void_p) for n in ("w1t", "b1", "w2t", "b2", "c1t", "cb1", "c2", "cb2", "w2", "logit_bound")]
 
 
 class ReturnsArgs(C.Structure):

@@ -159,16 +159,25 @@ int sy_env_set_policy(sy_env* env, const sy_mappo_weights* w, int32_t hidden) {
     if (!env) return fail(SY_ERR_INVALID, "sy_env_set_policy: null env%s");
     if (!w) {
         env->p.pw1t = env->p.pb1 = env->p.pw2 = env->p.pb2 = nullptr;
+        env->p.pbound = nullptr;
         env->p.pH = 0;
+        env->p.pslice = 0;
         return SY_OK;
     }
     if (!w->w1t || !w->b1 || !w->w2 || !w->b2) return fail(SY_ERR_INVALID, "sy_env_set_policy: w1t, b1, w2, b2 are required%s");
-    if (hidden < 4 || hidden > 64 || (hidden & 3)) return fail(SY_ERR_INVALID, "sy_env_set_policy: hidden must be a multiple of 4 in [4, 64]%s");
+    const bool pipeline_ok = env->p.N <= 256 && (env->wpb & 1) == 0;      // sy_kernels.hip::launch_engine_nr picks rollout3 then
+    const int hmax = pipeline_ok ? 128 : 64;
+    if (hidden < 4 || hidden > hmax || (hidden & 3))
+        return fail(SY_ERR_INVALID, "sy_env_set_policy: hidden must be a multiple of 4, at most 128 (64 on boards of more than 256 nodes)%s");
     if ((reinterpret_cast<uintptr_t>(w->w2) & 15) || (reinterpret_cast<uintptr_t>(w->w1t) & 15))
         return fail(SY_ERR_INVALID, "sy_env_set_policy: weights must be 16-byte aligned%s");
     if ((env->wpb & 1) != 0) return fail(SY_ERR_INVALID, "sy_env_set_policy: needs an even waves_per_block%s");
-    if (env->lds + (size_t)env->wpb * SY_POLICY_SLICE > kMaxLds) return fail(SY_ERR_INVALID, "sy_env_set_policy: no LDS left for the policy scratch%s");
+    const int pslice = pipeline_ok ? env->p.A * hidden * 4 + 128 : SY_POLICY_SLICE;
+    if (env->lds + (size_t)env->wpb * pslice > kMaxLds)
+        return fail(SY_ERR_INVALID, "sy_env_set_policy: no LDS left for the policy scratch (use a smaller waves_per_block)%s");
     env->p.pw1t = w->w1t; env->p.pb1 = w->b1; env->p.pw2 = w->w2; env->p.pb2 = w->b2;
+    env->p.pbound = w->logit_bound;
+    env->p.pslice = pslice;
     env->p.pH = hidden;
     return SY_OK;
 }

@@ -38,6 +38,8 @@ struct EngineParams {
     const float* pw2;             // [A][N][H]
     const float* pb2;             // [A][N]
     int32_t pH;
+    int32_t pslice;               // per-episode LDS scratch of the pipeline's policy path: A * H * 4 + 128 bytes
+    const float* pbound;          // [A] upper bound of any logit of actor a (the underflow rule's cheap test); may be null
     uint32_t* status;             // device status word (sy_env_bind_status); nullptr = failures are not reported
 };
 #define SY_POLICY_SLICE 2304      // per-episode LDS scratch of the in-kernel policy: 8 hidden vectors of 64 floats + slots

@@ -1628,6 +1628,260 @@ __device__ __forceinline__ void scan_eval_pair_policy(PairScanLane& q, const Pol
     wave_lds_fence();
 }
 
+// ---- the learned policy inside the pipeline (sy_env_set_policy) -----------------------------------
+// The move wave evaluates the MAPPO actors for the next observation (mappo_agent.py:87-142 inside the rollout loop
+// of mappo_trainer.py:161-287); everything that reads the board for the RECORD (visit counters, shortest paths,
+// rewards) moves to the helper wave, so the move wave has the registers to keep a whole second-layer row per lane in
+// flight.  Per step and agent: hidden = relu(b1 + row lookups in w1t) (lane = hidden unit; up to 128 units, kept in
+// LDS), one H-term dot product per scan lane against its neighbour's row of w2 (two 16-byte pieces of both
+// episodes' rows per round trip to L2), a Gumbel-max draw and a log-sum-exp over the agent's lane group through LDS
+// slots: the softmax over the legal actions == the reference's masked, renormalised softmax.
+// The reference's underflow rule (mappo_agent.py:123-134: if the legal actions hold <= 1e-8 of the softmax mass, the
+// action is drawn uniformly over the mask) needs the mass of ALL nodes.  `bound[a]` (host, refreshed with the weights)
+// is an upper bound of any logit of actor a over all observations; while
+//     logsumexp(legal) > log(1e-8) + log(N) + bound[a]
+// the legal mass provably exceeds 1e-8 and nothing else is evaluated; otherwise (rare) the wave evaluates actor a's
+// N logits for that episode exactly and applies the reference's rule.
+// Per-episode LDS scratch: [A][H] hidden floats, then 8 x {max key, max logit, sum exp, log-prob of the winner}.
+struct PolLane3 {
+    uint32_t hs0, hs1;       // my group's agent's hidden vector, episode 0 / 1
+    uint32_t sl0, sl1;       // my group's agent's slots, episode 0 / 1
+    uint32_t slr;            // slots of agent (lane & 7) of my half (agent-lane role)
+    const float* w2a;        // my group's agent's second layer [N][H]
+    const float* b2a;
+    float thr;               // log(1e-8) + log(N) + bound[agent]   (+inf without a bound: never the exact path)
+    int ag;
+};
+__device__ __forceinline__ PolLane3 make_pol_lane3(const EngineParams& p, const ScanMap& sm, int lane, int A, uint32_t pol0,
+                                                   uint32_t pol1) {
+    PolLane3 q;
+    const int H = p.pH;
+    q.ag = (sm.live && sm.grp < A) ? sm.grp : 0;
+    q.hs0 = pol0 + (uint32_t)(q.ag * H) * 4u;
+    q.hs1 = pol1 + (uint32_t)(q.ag * H) * 4u;
+    const uint32_t slots = (uint32_t)(A * H) * 4u;
+    q.sl0 = pol0 + slots + 16u * (uint32_t)q.ag;
+    q.sl1 = pol1 + slots + 16u * (uint32_t)q.ag;
+    q.slr = (lane >= 32 ? pol1 : pol0) + slots + 16u * (uint32_t)(lane & 7);
+    q.w2a = p.pw2 + (size_t)q.ag * p.N * H;
+    q.b2a = p.pb2 + (size_t)q.ag * p.N;
+    q.thr = p.pbound ? (-18.420680744f + __logf((float)p.N) + p.pbound[q.ag]) : -3.0e38f;
+    return q;
+}
+__device__ __forceinline__ void policy_hidden_pair3(const EngineParams& p, int P, int A, int pos_n, int lane, uint32_t pol0,
+                                                    uint32_t pol1) {
+    // All row lookups of a half are issued back to back (1 + P * P rows of w1t and the A biases: every load is
+    // independent) and summed afterwards: one round trip to L2 per half instead of one per row.
+    const int H = p.pH, N = p.N;
+    for (int k0 = 0; k0 < H; k0 += 64) {      // (one pass up to 64 hidden units, two for 128)
+        const bool hk = k0 + lane < H;
+        const int k = hk ? k0 + lane : 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t pb = h ? pol1 : pol0;
+            int pj[SY_MAX_AGENTS];
+#pragma unroll
+            for (int j = 0; j < SY_MAX_AGENTS; ++j) pj[j] = j <= P ? rdlane(pos_n, 32 * h + j) : 0;
+            float bias[SY_MAX_AGENTS], row[SY_MAX_AGENTS][SY_MAX_AGENTS];
+#pragma unroll
+            for (int a = 0; a < SY_MAX_AGENTS; ++a) {
+                bias[a] = a <= P ? p.pb1[a * H + k] : 0.0f;
+#pragma unroll
+                for (int j = 0; j < SY_MAX_AGENTS; ++j) row[a][j] = 0.0f;
+            }
+            row[0][0] = p.pw1t[(size_t)pj[0] * H + k];                         // MrX's actor: one-hot MrX node
+#pragma unroll
+            for (int a = 1; a < SY_MAX_AGENTS; ++a) {
+                if (a <= P) {
+                    const float* w1a = p.pw1t + (size_t)a * N * H;             // police actors: multi-hot police nodes
+#pragma unroll
+                    for (int j = 1; j < SY_MAX_AGENTS; ++j)
+                        if (j <= P) row[a][j] = w1a[(size_t)pj[j] * H + k];
+                }
+            }
+            {
+                const float v = bias[0] + row[0][0];
+                if (hk) *lds_at<float>(pb + 4u * (uint32_t)k) = v > 0.0f ? v : 0.0f;
+            }
+#pragma unroll
+            for (int a = 1; a < SY_MAX_AGENTS; ++a) {
+                if (a <= P) {
+                    float u = bias[a];
+#pragma unroll
+                    for (int j = 1; j < SY_MAX_AGENTS; ++j)
+                        if (j <= P) u += row[a][j];                            // same order as the sequential sum
+                    if (hk) *lds_at<float>(pb + 4u * (uint32_t)(a * H + k)) = u > 0.0f ? u : 0.0f;
+                }
+            }
+        }
+    }
+}
+// The exact softmax mass of the legal actions of one (episode, agent): all N logits of the actor on the wave
+// (node = lane + 64 r), float32 like the reference's tensors.  legal_lse = logsumexp of the legal logits.
+#ifdef SY_POL_EXACT_INLINE
+#define SY_EXACT_ATTR __forceinline__
+#else
+#define SY_EXACT_ATTR __noinline__     // a call keeps the cold path's registers out of the step loop (3.15 vs 2.97 G agent-steps/s)
+#endif
+template <int NR>
+__device__ SY_EXACT_ATTR float exact_legal_mass(const float* w2a, const float* b2a, uint32_t hs, int H, int N, int lane, float legal_lse) {
+    float l[NR];
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int n = lane + 64 * r;
+        const int nn = n < N ? n : N - 1;
+        float acc = b2a[nn];
+        const float* row = w2a + (size_t)nn * H;
+        for (int k = 0; k < H; k += 4) {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            const f4 wv = *reinterpret_cast<const f4*>(row + k);
+            const f4 hv = *lds_at<f4>(hs + 4u * (uint32_t)k);
+            acc = fmaf(wv.x, hv.x, acc); acc = fmaf(wv.y, hv.y, acc); acc = fmaf(wv.z, hv.z, acc); acc = fmaf(wv.w, hv.w, acc);
+        }
+        l[r] = n < N ? acc : -3.0e38f;
+        mx = l[r] > mx ? l[r] : mx;
+    }
+#pragma unroll
+    for (int o2 = 32; o2 >= 1; o2 >>= 1) {
+        const float om = __shfl_xor(mx, o2, kWave);
+        mx = om > mx ? om : mx;
+    }
+    float z = 0.0f;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) z += (lane + 64 * r < N) ? __expf(l[r] - mx) : 0.0f;
+    z = wave_sum(z);
+    return __expf(legal_lse - mx) / z;
+}
+
+// scan_eval_pair1 with the learned policy choosing the action (single pass).
+template <int NR>
+__device__ __forceinline__ void scan_eval_pair_policy3(PairScanLane& q, const PolLane3& pl, const ScanMap& sm, int gw, int H, int N,
+                                                       int lane, const float* w2_all, const float* b2_all, const ScanPairIn& g,
+                                                       int& act_v, int& cost_v, int& quirk_cnt, float& logp_v) {
+    if (lanes(kAgentSlots)) {
+        *lds_at<uint64_t>(q.selr) = 0x0000ffffull;                                   // "no move": action -1, cost 0
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        *lds_at<v4i>(pl.slr) = (v4i){(int)0x80000000, (int)0x80000000, 0, 0};         // max key, max logit, sum exp, log-prob
+    }
+    *lds_at<uint8_t>(q.prev0) = 0;
+    *lds_at<uint8_t>(q.prev1) = 0;
+    const uint32_t fmask = (1u << gw) - 1u;
+    const int w0 = (int)(g.ent0 >> 16), w1 = (int)(g.ent1 >> 16);
+    const uint64_t bo0 = bal(w0 <= g.ma0) & q.on_m, bo1 = bal(w1 <= g.ma1) & q.on_m;
+    const uint64_t bq0 = bal(w0 <= g.mq0) & q.on_m, bq1 = bal(w1 <= g.mq1) & q.on_m;
+    const bool own0 = lanes(bo0), own1 = lanes(bo1);
+    const uint32_t nb0 = own0 ? (g.ent0 & 0xffffu) : 0u, nb1 = own1 ? (g.ent1 & 0xffffu) : 0u;
+    const uint32_t n0 = own0 ? q.row0 + nb0 : q.scratch, n1 = own1 ? q.row1 + nb1 : q.scratch;
+    *lds_at<uint8_t>(n0) = 1;
+    *lds_at<uint8_t>(n1) = 1;
+    q.prev0 = n0;
+    q.prev1 = n1;
+    // one logit per affordable entry: the neighbour's row of w2 (L2) against the agent's hidden vector (LDS); a few
+    // 16-byte pieces of both rows are in flight per round trip
+    float l0 = pl.b2a[nb0], l1 = pl.b2a[nb1];
+    {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const f4* r0 = reinterpret_cast<const f4*>(pl.w2a + (size_t)nb0 * H);
+        const f4* r1 = reinterpret_cast<const f4*>(pl.w2a + (size_t)nb1 * H);
+        const int nq = H >> 2;
+        int c = 0;
+#ifndef SY_POL_BATCH
+#define SY_POL_BATCH 2      // measured (tools/policy_rollout_bench.py, H = 64): 1 -> 2.7, 2 -> 3.2, 4 -> 2.4, 8 -> 2.1 G agent-steps/s:
+#endif                      // more pieces in flight cost more registers than the round trips they save
+        for (; c + SY_POL_BATCH <= nq; c += SY_POL_BATCH) {
+            f4 a[SY_POL_BATCH], b[SY_POL_BATCH];
+#pragma unroll
+            for (int u = 0; u < SY_POL_BATCH; ++u) { a[u] = r0[c + u]; b[u] = r1[c + u]; }
+#pragma unroll
+            for (int u = 0; u < SY_POL_BATCH; ++u) {
+                const f4 h0 = *lds_at<f4>(pl.hs0 + 16u * (uint32_t)(c + u)), h1 = *lds_at<f4>(pl.hs1 + 16u * (uint32_t)(c + u));
+                l0 = fmaf(a[u].x, h0.x, l0); l0 = fmaf(a[u].y, h0.y, l0); l0 = fmaf(a[u].z, h0.z, l0); l0 = fmaf(a[u].w, h0.w, l0);
+                l1 = fmaf(b[u].x, h1.x, l1); l1 = fmaf(b[u].y, h1.y, l1); l1 = fmaf(b[u].z, h1.z, l1); l1 = fmaf(b[u].w, h1.w, l1);
+            }
+        }
+        for (; c < nq; ++c) {
+            const f4 a0 = r0[c], a1 = r1[c];
+            const f4 h0 = *lds_at<f4>(pl.hs0 + 16u * (uint32_t)c), h1 = *lds_at<f4>(pl.hs1 + 16u * (uint32_t)c);
+            l0 = fmaf(a0.x, h0.x, l0); l0 = fmaf(a0.y, h0.y, l0); l0 = fmaf(a0.z, h0.z, l0); l0 = fmaf(a0.w, h0.w, l0);
+            l1 = fmaf(a1.x, h1.x, l1); l1 = fmaf(a1.y, h1.y, l1); l1 = fmaf(a1.z, h1.z, l1); l1 = fmaf(a1.w, h1.w, l1);
+        }
+    }
+    if (own0) atomicMax(lds_at_generic<int>(pl.sl0 + 4u), f32_ordered(l0));
+    if (own1) atomicMax(lds_at_generic<int>(pl.sl1 + 4u), f32_ordered(l1));
+    wave_lds_fence();
+    float L0 = ordered_f32(*lds_at<int>(pl.sl0 + 4u)), L1 = ordered_f32(*lds_at<int>(pl.sl1 + 4u));
+    if (own0) atomicAdd(lds_at_generic<float>(pl.sl0 + 8u), __expf(l0 - L0));
+    if (own1) atomicAdd(lds_at_generic<float>(pl.sl1 + 8u), __expf(l1 - L1));
+    wave_lds_fence();
+    float S0 = *lds_at<float>(pl.sl0 + 8u), S1 = *lds_at<float>(pl.sl1 + 8u);
+    // ---- the reference's underflow rule (mappo_agent.py:123-134), exact only where the cheap bound cannot rule it out
+    {
+        const bool lead = lanes(q.lead_m);
+        const uint32_t gf0 = (uint32_t)(bo0 >> sm.gsh) & fmask, gf1 = (uint32_t)(bo1 >> sm.gsh) & fmask;
+        const uint64_t sus0 = bal(lead && gf0 != 0u && !(L0 + __logf(S0) > pl.thr));
+        const uint64_t sus1 = bal(lead && gf1 != 0u && !(L1 + __logf(S1) > pl.thr));
+        uint64_t fb0 = 0ull, fb1 = 0ull;            // groups (leader-lane bits) that fall back to uniform over the mask
+#ifdef SY_POL_NO_FALLBACK
+        if (false) {
+#else
+        if ((sus0 | sus1) != 0ull) {                // rare: evaluate the suspicious actors exactly, one (episode, agent) at a time
+#endif
+            for (int h = 0; h < 2; ++h) {
+                uint64_t todo = h ? sus1 : sus0;
+                while (todo != 0ull) {
+                    const int ll = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    const int ag = rdlane(pl.ag, ll);
+                    const uint32_t hs = (uint32_t)rdlane((int)(h ? pl.hs1 : pl.hs0), ll);
+                    const float lse = __int_as_float(rdlane(__float_as_int(h ? L1 + __logf(S1) : L0 + __logf(S0)), ll));
+                    const float* w2u = w2_all + (size_t)ag * N * H;       // actor `ag` (wave-uniform)
+                    const float* b2u = b2_all + (size_t)ag * N;
+                    const float mass = exact_legal_mass<NR>(w2u, b2u, hs, H, N, lane, lse);
+                    if (mass <= 1e-8f) { if (h) fb1 |= 1ull << ll; else fb0 |= 1ull << ll; }
+                }
+            }
+        }
+        if ((fb0 | fb1) != 0ull) {                  // my group's leader bit -> my fallback flag
+            const int lead_lane = lane - sm.col;    // the first lane of my group
+            const bool f0 = ((fb0 >> lead_lane) & 1ull) != 0ull, f1 = ((fb1 >> lead_lane) & 1ull) != 0ull;
+            l0 = f0 ? 0.0f : l0; L0 = f0 ? 0.0f : L0; S0 = f0 ? (float)__popc(gf0) : S0;
+            l1 = f1 ? 0.0f : l1; L1 = f1 ? 0.0f : L1; S1 = f1 ? (float)__popc(gf1) : S1;
+        }
+    }
+    // Gumbel-max draw: a cheap per-lane hash of the agent's Philox word of this step
+    auto gumbel = [&sm](uint32_t x) {
+        uint32_t h = x ^ ((uint32_t)sm.col * 0x9E3779B9u) ^ 0x85EBCA6Bu;
+        h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+        const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        return -__logf(-__logf(u));
+    };
+    const float k0 = l0 + gumbel(g.xa0), k1 = l1 + gumbel(g.xa1);
+    if (own0) atomicMax(lds_at_generic<int>(pl.sl0), f32_ordered(k0));
+    if (own1) atomicMax(lds_at_generic<int>(pl.sl1), f32_ordered(k1));
+    wave_lds_fence();
+    const bool win0 = own0 && f32_ordered(k0) == *lds_at<int>(pl.sl0), win1 = own1 && f32_ordered(k1) == *lds_at<int>(pl.sl1);
+    if (win0) {
+        *lds_at<int>(q.selw0) = (int)g.ent0;
+        *lds_at<float>(pl.sl0 + 12u) = (l0 - L0) - __logf(S0);
+    }
+    if (win1) {
+        *lds_at<int>(q.selw1) = (int)g.ent1;
+        *lds_at<float>(pl.sl1 + 12u) = (l1 - L1) - __logf(S1);
+    }
+    if (lanes(q.lead_m)) {
+        lds_at<int>(q.selw0)[1] = __popc((uint32_t)(bq0 >> sm.gsh) & fmask);
+        lds_at<int>(q.selw1)[1] = __popc((uint32_t)(bq1 >> sm.gsh) & fmask);
+    }
+    wave_lds_fence();
+    const uint64_t r = *lds_at<uint64_t>(q.selr);
+    act_v = (int)(int16_t)(uint32_t)r;              // 0xffff -> -1
+    cost_v = (int)(((uint32_t)r) >> 16);
+    quirk_cnt = (int)(r >> 32);
+    logp_v = *lds_at<float>(pl.slr + 12u);
+    wave_lds_fence();
+}
+
 __device__ __forceinline__ int hbcast(int v, int src_local, bool upper) {   // v of local lane src_local of my half
     const int lo = rdlane(v, src_local), hi = rdlane(v, 32 + src_local);
     return upper ? hi : lo;
@@ -1856,9 +2110,9 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
     // in-kernel policy: per-episode scratch behind the episode slices
     const uint32_t pol0 = lds_off(L.env_base) + (uint32_t)wpb * (uint32_t)p.wave_lds_bytes + (uint32_t)slot * SY_POLICY_SLICE;
     const uint32_t pol1 = pol0 + SY_POLICY_SLICE;
-    PolicyLane pll;
+    PolLane3 pll;
     float logp_v = 0.0f;
-    if (POL) pll = make_policy_lane(p, sm, lane, A, pol0, pol1);
+    if (POL) pll = make_pol_lane3(p, sm, lane, A, pol0, pol1);
     if (one_pass || two_pass) {
         for (int i = lane; i < n16; i += kWave) {
             reinterpret_cast<uint4*>(E.mrow)[i] = make_uint4(0, 0, 0, 0);
@@ -1867,9 +2121,9 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         wave_lds_fence();
         const ScanPairIn g0 = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, draw_word(sc_v));
         if (POL) {           // (the launcher only picks this instance for single-pass boards)
-            policy_hidden_pair(p, P, pos_v, lane, pol0, pol1);
+            policy_hidden_pair3(p, P, A, pos_v, lane, pol0, pol1);
             wave_lds_fence();
-            scan_eval_pair_policy(psl, pll, sm, p.scan_w, p.pH, g0, act_v, cost_v, qcnt, logp_v);
+            scan_eval_pair_policy3<NR>(psl, pll, sm, p.scan_w, p.pH, N, lane, p.pw2, p.pb2, g0, act_v, cost_v, qcnt, logp_v);
         } else if (one_pass) {
             scan_eval_pair1(psl, sm, p.scan_w, g0, act_v, cost_v, qcnt);
         } else {
@@ -1957,7 +2211,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         const ScanPairIn sg = scan_gather_pair(L.ell_s, A, sm, 0, pos_n, mon_n, x_next);
         ScanPairIn sg2 = sg;
         if (two_pass) sg2 = scan_gather_pair(L.ell_s, A, sm, sm.per_pass, pos_n, mon_n, x_next);
-        if (POL) policy_hidden_pair(p, P, pos_n, ln, pol0, pol1);      // hidden vectors of the next observation
+        if (POL) policy_hidden_pair3(p, P, A, pos_n, ln, pol0, pol1);      // hidden vectors of the next observation
         SY_STAMP(1)
         int vc = 0;
         if (is_pol) {                                                         // :244-245
@@ -2008,7 +2262,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         int act_n = -1, cost_n = 0;
         float logp_n = 0.0f;
         if (POL) {
-            scan_eval_pair_policy(psl, pll, sm, p.scan_w, p.pH, sg, act_n, cost_n, qcnt, logp_n);
+            scan_eval_pair_policy3<NR>(psl, pll, sm, p.scan_w, p.pH, N, ln, p.pw2, p.pb2, sg, act_n, cost_n, qcnt, logp_n);
         } else if (one_pass) {
             scan_eval_pair1(psl, sm, p.scan_w, sg, act_n, cost_n, qcnt);
         } else if (two_pass) {
@@ -2158,9 +2412,9 @@ static constexpr int kFlagTerm = 1, kFlagWinShift = 2, kFlagRestart = 16, kFlagR
 #endif
 
 // ---- the move wave -----------------------------------------------------------------------------
-template <bool REC, int PT>
+template <int NR, bool REC, int PT, bool POL>
 __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& L, const EnvLds& E, const EnvLds& E1, int lane, int e,
-                                           int g, int T, sy_rollout_buffers out) {
+                                           int g, int slot, int T, sy_rollout_buffers out) {
     const int P = PT > 0 ? PT : p.P, A = P + 1;
     const int N = p.N, NS = p.NS, B = p.B;
     const bool live1 = e + 1 < B;
@@ -2190,7 +2444,14 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
     int t_v = p.st.t[eh];
     uint32_t sc_v = p.st.step_count[eh];
     uint32_t* const vis32 = reinterpret_cast<uint32_t*>(vis_h);   // 32-bit counters: one returning LDS add per step
-    for (int i = a0; i < NS; i += 32) vis32[i] = p.st.visits[(size_t)eh * NS + i];
+    if (!POL)
+        for (int i = a0; i < NS; i += 32) vis32[i] = p.st.visits[(size_t)eh * NS + i];
+    // in-kernel policy: per-episode scratch behind the episode slices
+    const uint32_t pol0 = lds_off(L.env_base) + (uint32_t)p.wpb * (uint32_t)p.wave_lds_bytes + (uint32_t)slot * (uint32_t)p.pslice;
+    const uint32_t pol1 = pol0 + (uint32_t)p.pslice;
+    PolLane3 pll;
+    float logp_v = 0.0f;
+    if (POL) pll = make_pol_lane3(p, sm, lane, A, pol0, pol1);
     int rev_v = p.reveal_k > 0 ? p.reveal_k - (t_v % p.reveal_k) : 0;
     uint32_t xw[4];
     philox4(gid, sc_v >> 2, kPurposeAct, (uint32_t)a0, p.seed_lo, p.seed_hi, xw);
@@ -2211,7 +2472,11 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
     int act_v = -1, cost_v = 0, qcnt = 0;
     {
         const ScanPairIn g0 = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, draw_word(sc_v));
-        if (one_pass) {
+        if (POL) {           // (the launcher only picks this instance for single-pass boards)
+            policy_hidden_pair3(p, P, A, pos_v, lane, pol0, pol1);
+            wave_lds_fence();
+            scan_eval_pair_policy3<NR>(psl, pll, sm, p.scan_w, p.pH, N, lane, p.pw2, p.pb2, g0, act_v, cost_v, qcnt, logp_v);
+        } else if (one_pass) {
             scan_eval_pair1(psl, sm, p.scan_w, g0, act_v, cost_v, qcnt);
         } else {
             const ScanPairIn g1 = scan_gather_pair(L.ell_s, A, sm, sm.per_pass, pos_v, mon_v, draw_word(sc_v));
@@ -2219,14 +2484,21 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
             scan_eval_pair1<false, true>(psl2, sm, p.scan_w, g1, act_v, cost_v, qcnt);
         }
     }
-    // E[k] = the observation before step k, the action of step k, and what step k - 1 produced (reward, outcome marks)
+    // E[k] = the observation before step k, the action of step k, and what step k - 1 produced: the reward and the
+    // outcome marks — or, with the learned policy (the helper evaluates the rewards then), the position-reward counts
+    // of the observation and the log-probability of the action
     auto publish = [&](int k, int pos, int act, int mon, double reward, int t_and_flags) {
         if (lanes(kAgentSlots)) {
             typedef int v4i __attribute__((ext_vector_type(4)));
             const int w0 = (pos & 0xffff) | (act << 16);
-            const int w1 = (lane & 31) == 0 ? t_and_flags : mon;
-            *lds_at<v4i>(ring_w + (uint32_t)(k & (kRing3 - 1)) * kEntry3) =
-                (v4i){w0, w1, __double2loint(reward), __double2hiint(reward)};
+            if (POL) {
+                const int w1 = (lane & 31) == 0 ? (t_and_flags | (qcnt << kMetaCntShift)) : (mon | (qcnt << 16));
+                *lds_at<v4i>(ring_w + (uint32_t)(k & (kRing3 - 1)) * kEntry3) = (v4i){w0, w1, __float_as_int(logp_v), 0};
+            } else {
+                const int w1 = (lane & 31) == 0 ? t_and_flags : mon;
+                *lds_at<v4i>(ring_w + (uint32_t)(k & (kRing3 - 1)) * kEntry3) =
+                    (v4i){w0, w1, __double2loint(reward), __double2hiint(reward)};
+            }
         }
         asm volatile("" ::: "memory");
 #ifdef SY_INJECT_LOST_HANDOFF   // fault-injection build (tests only): episode 0 stops publishing after entry 2
@@ -2331,30 +2603,33 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         const ScanPairIn sg = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, x_next);
         ScanPairIn sg2 = sg;
         if (!one_pass) sg2 = scan_gather_pair(L.ell_s, A, sm, sm.per_pass, pos_v, mon_v, x_next);
+        if (POL) policy_hidden_pair3(p, P, A, pos_v, ln, pol0, pol1);      // hidden vectors of the next observation
         S3(2)
         // ---- node_visit_counts (yard.py:244-245), then every agent's post-move node to every lane of its half through
         // LDS (the result-slot words of the staging row, free until the scan is evaluated), then the shortest-path gathers
         int vc = 0;
-        if (is_pol) vc = (int)atomicAdd(vis32 + pos_m, 1u) + 1;
-        if (NEED != 0ull) {                // a new episode starts from zero (yard.py:85)
-            if (lanes(NEED))
-                for (int i = a; i < (NS >> 2); i += 32) reinterpret_cast<uint4*>(vis32)[i] = make_uint4(0, 0, 0, 0);
-        }
-        if (lanes(kAgentSlots)) lds_at<int>(xch_off)[a] = pos_m;
-        wave_lds_fence();
-        typedef int v4i __attribute__((ext_vector_type(4)));
-        const v4i qa = *lds_at<v4i>(xch_off), qb = *lds_at<v4i>(xch_off + 16u);
-        const int q[SY_MAX_AGENTS] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-        const uint32_t rowb = (uint32_t)(pos_m * N) * 2u;
         int dm = 0;
         int dj[SY_MAX_AGENTS - 1];
 #pragma unroll
         for (int j = 1; j < SY_MAX_AGENTS; ++j) dj[j - 1] = 0;
-        if (is_pol) {
-            dm = (int)*at_bytes(ap, rowb + (uint32_t)q[0] * 2u);
+        if (!POL) {
+            if (is_pol) vc = (int)atomicAdd(vis32 + pos_m, 1u) + 1;
+            if (NEED != 0ull) {                // a new episode starts from zero (yard.py:85)
+                if (lanes(NEED))
+                    for (int i = a; i < (NS >> 2); i += 32) reinterpret_cast<uint4*>(vis32)[i] = make_uint4(0, 0, 0, 0);
+            }
+            if (lanes(kAgentSlots)) lds_at<int>(xch_off)[a] = pos_m;
+            wave_lds_fence();
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            const v4i qa = *lds_at<v4i>(xch_off), qb = *lds_at<v4i>(xch_off + 16u);
+            const int q[SY_MAX_AGENTS] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+            const uint32_t rowb = (uint32_t)(pos_m * N) * 2u;
+            if (is_pol) {
+                dm = (int)*at_bytes(ap, rowb + (uint32_t)q[0] * 2u);
 #pragma unroll
-            for (int j = 1; j < SY_MAX_AGENTS; ++j)
-                if (j <= P) dj[j - 1] = (int)*at_bytes(ap, rowb + (uint32_t)q[j] * 2u);
+                for (int j = 1; j < SY_MAX_AGENTS; ++j)
+                    if (j <= P) dj[j - 1] = (int)*at_bytes(ap, rowb + (uint32_t)q[j] * 2u);
+            }
         }
         // ---- the mask rows of the observation before the step go to the record (LDS operations of a wave are in
         // order: these reads see the rows before the scan below rewrites them)
@@ -2377,7 +2652,9 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         }
         S3(3)
         // ---- evaluate half of the scan: masks of the new state, position-reward counts, next action
-        if (one_pass) {
+        if (POL) {
+            scan_eval_pair_policy3<NR>(psl, pll, sm, p.scan_w, p.pH, N, ln, p.pw2, p.pb2, sg, act_v, cost_v, qcnt, logp_v);
+        } else if (one_pass) {
             scan_eval_pair1(psl, sm, p.scan_w, sg, act_v, cost_v, qcnt);
         } else {
             scan_eval_pair1<true, false>(psl, sm, p.scan_w, sg, act_v, cost_v, qcnt);
@@ -2385,8 +2662,10 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         }
         S3(4)
         // ---- rewards of the step (reward_calculator.py:63-90 constants, :94-266 shaped)
-        const double shaped = shaped_reward3(tb, a, P, POLM, t_rew, qcnt, vc, dm, dj, kc);
-        rew = lanes(ENDED) ? (lanes(CAP) ? (a == 0 ? -1.0 : 1.0) : (a == 0 ? 1.0 : 0.0)) : shaped;
+        if (!POL) {
+            const double shaped = shaped_reward3(tb, a, P, POLM, t_rew, qcnt, vc, dm, dj, kc);
+            rew = lanes(ENDED) ? (lanes(CAP) ? (a == 0 ? -1.0 : 1.0) : (a == 0 ? 1.0 : 0.0)) : shaped;
+        }
         S3(6)
         // ---- hand the new state and the step's outcome to the helper.  Back-pressure: every kRing3 / 2 entries make sure
         // the helper is at most kRing3 / 2 entries behind, so the ring cannot be overrun in between.
@@ -2411,7 +2690,7 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         if (a0 < A) {
             kq->st.pos[(size_t)eh * A + a0] = pos_v;
             kq->st.budget[(size_t)eh * A + a0] = mon_v;
-            kq->st.reward[(size_t)eh * A + a0] = rew;
+            if (!POL) kq->st.reward[(size_t)eh * A + a0] = rew;
         }
         if (a0 == 0) {
             kq->st.t[eh] = t_v;
@@ -2420,8 +2699,10 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
             kq->st.truncated[eh] = (uint8_t)trunc_v;
             kq->st.winner[eh] = (int8_t)win_v;
         }
-        uint16_t* vis_out = kq->st.visits;
-        for (int i = a0; i < NS; i += 32) vis_out[(size_t)eh * NS + i] = (uint16_t)vis32[i];
+        if (!POL) {
+            uint16_t* vis_out = kq->st.visits;
+            for (int i = a0; i < NS; i += 32) vis_out[(size_t)eh * NS + i] = (uint16_t)vis32[i];
+        }
         uint4* dst = reinterpret_cast<uint4*>(kq->st.mask + (size_t)eh * A * NS);
         for (int i = a0; i < n16; i += 32) dst[i] = reinterpret_cast<const uint4*>(mrow_h)[i];
     }
@@ -2594,8 +2875,11 @@ struct BeliefLanes {
 
 // ---- the helper wave ---------------------------------------------------------------------------
 // Everything that only leaves the chip: the belief filter with its record rows, and the packed record row of every
-// transition {reward, pos, budget, action, t, flags} (the move wave hands over the reward it computed).
-template <int NR, bool REC, int PT>
+// transition {reward, pos, budget, action, t, flags} (the move wave hands over the reward it computed).  POL (the
+// move wave evaluates the learned policy): the helper also counts visits, gathers the shortest paths and evaluates
+// the rewards itself (entry k + 1 holds the post-move nodes and the position-reward counts), and records the
+// log-probabilities.
+template <int NR, bool REC, int PT, bool POL>
 __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap& L, const EnvLds& E, const EnvLds& E1, int lane, int e,
                                              int g, int T, sy_rollout_buffers out) {
     const int P = PT > 0 ? PT : p.P, A = P + 1;
@@ -2605,7 +2889,21 @@ __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap
     const int a0 = lane & 31;
     const int eh = (upper0 && live1) ? e + 1 : e;
     const bool store_ok = !upper0 || live1;
-    const uint32_t ring_r = lds_off(upper0 ? E1.ring : E.ring) + (uint32_t)(a0 & 7) * 16u;   // my agent slot inside an entry
+    const uint32_t ring_h = lds_off(upper0 ? E1.ring : E.ring);
+    const uint32_t ring_r = ring_h + (uint32_t)(a0 & 7) * 16u;              // my agent slot inside an entry
+    // POL: the reward side of the step
+    const uint16_t* __restrict__ ap = p.apsp + (size_t)g * N * N;
+    Coefs<true> kc;
+    kc.s = L.kc_s + (a0 == 0 ? 0 : 8);
+    RewardTabs tb;
+    tb.exp_s = L.exp_s; tb.cov_s = L.cov_s; tb.nrc_s = L.nrc_s; tb.nra_s = L.nra_s; tb.px_s = L.px_s;
+    tb.exp_g = p.exp_tab; tb.cov_g = p.cov_tab; tb.n_exp = p.n_exp; tb.n_cov = p.n_cov;
+    uint32_t* const vis32 = reinterpret_cast<uint32_t*>(upper0 ? E1.vis_s : E.vis_s);
+    if (POL)
+        for (int i = a0; i < NS; i += 32) vis32[i] = p.st.visits[(size_t)eh * NS + i];
+    const uint64_t POLM = (((1ull << P) - 1ull) << 1) * 0x0000000100000001ull;
+    double rew = 0.0;
+    float logp0_v = 0.0f;
     const bool has_belief = p.st.belief != nullptr;
     BeliefLanes<NR> bl;
     if (has_belief) bl.load(p, L, E, lane, e, g, live1);
@@ -2634,6 +2932,10 @@ __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap
         mon0_v = (lane & 31) == 0 ? SY_MRX_MONEY : w.y;
         const int m_lo = rdlane(w.y, 0), m_hi = rdlane(w.y, 32);
         t0_v = (upper0 ? m_hi : m_lo) & kMetaTimeMask;
+        if (POL) {
+            mon0_v = (lane & 31) == 0 ? SY_MRX_MONEY : (w.y & 0xffff);
+            logp0_v = __int_as_float(w.z);
+        }
         asm volatile("" ::: "memory");
         if (lane < 2) lds_poke(lane == 0 ? E.sync + 1 : E1.sync + 1, 1);
     }
@@ -2663,33 +2965,45 @@ __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap
         // ---- what step s produced: entry s + 1 (the next observation, the reward, the outcome marks)
         wait_entry(s + 1);
         S3(1)
-        const v4i w = *lds_at<v4i>(ring_r + (uint32_t)((s + 1) & (kRing3 - 1)) * kEntry3);
+        const uint32_t ent = (uint32_t)((s + 1) & (kRing3 - 1)) * kEntry3;
+        const v4i w = *lds_at<v4i>(ring_r + ent);
+        int q[SY_MAX_AGENTS];                 // POL: every agent's post-move node of my half (the entry's slots)
+#pragma unroll
+        for (int j = 0; j < SY_MAX_AGENTS; ++j) q[j] = POL ? (*lds_at<int>(ring_h + ent + 16u * (uint32_t)j) & 0xffff) : 0;
         asm volatile("" ::: "memory");
         if (lane < 2) lds_poke(lane == 0 ? E.sync + 1 : E1.sync + 1, s + 2);   // entry copied: the slot may be reused
         const int pos1_v = w.x & 0xffff, act1_v = w.x >> 16;                   // arithmetic shift: 0xffff -> -1
         const int m_lo = rdlane(w.y, 0), m_hi = rdlane(w.y, 32);
         const int meta_v = upper ? m_hi : m_lo;
-        const int mon1_v = a == 0 ? SY_MRX_MONEY : w.y;
+        const int mon1_v = a == 0 ? SY_MRX_MONEY : (POL ? (w.y & 0xffff) : w.y);
         const int fl_v = meta_v >> kMetaFlagShift;
         const int f_lo = m_lo >> kMetaFlagShift, f_hi = m_hi >> kMetaFlagShift;     // wave-uniform copies
         S3(2)
-        // ---- the packed record row of the transition
-        if (REC) {
-            int* rdst = at_bytes(out.record, off_rec);
-            if (store_ok) {
-                if (a < A) {
-                    typedef int v2i __attribute__((ext_vector_type(2)));
-                    *reinterpret_cast<v2i*>(rdst + 2 * a) = (v2i){w.z, w.w};      // the float64 reward
-                    rdst[2 * A + a] = pos0_v;
-                    rdst[3 * A + a] = mon0_v;
-                    rdst[4 * A + a] = act0_v;
-                }
-                if (a < RW - 5 * A)
-                    rdst[5 * A + a] = a == 0 ? t0_v : (a == 1 ? (fl_v & kFlagTerm) : (a == 2 ? ((fl_v >> 1) & 1) : (a == 3 ? ((fl_v >> kFlagWinShift) & 3) : 0)));
+        int rw_lo = w.z, rw_hi = w.w;         // the float64 reward of the transition (from the move wave, or evaluated here)
+        int dm = 0, vc = 0;
+        int dj[SY_MAX_AGENTS - 1];
+#pragma unroll
+        for (int j = 1; j < SY_MAX_AGENTS; ++j) dj[j - 1] = 0;
+        bool do_shaped = false;
+        if (POL) {
+            const bool is_pol = a >= 1 && a <= P;
+            const bool restart_v = (fl_v & kFlagRestart) != 0;
+            do_shaped = ((f_lo & (kFlagTerm | 2)) == 0) || ((f_hi & (kFlagTerm | 2)) == 0);
+            // shortest paths between the post-move nodes (reward_calculator.py:126-202): issued now, used after the belief
+            if (do_shaped && is_pol) {
+                const uint32_t rowb = (uint32_t)(pos1_v * N) * 2u;
+                dm = (int)*at_bytes(ap, rowb + (uint32_t)q[0] * 2u);
+#pragma unroll
+                for (int j = 1; j < SY_MAX_AGENTS; ++j)
+                    if (j <= P) dj[j - 1] = (int)*at_bytes(ap, rowb + (uint32_t)q[j] * 2u);
             }
-            out.record += (size_t)B * RW;
+            // node_visit_counts (yard.py:244-245): post-move police nodes; a new episode starts from zero (yard.py:85)
+            if (((f_lo | f_hi) & kFlagRestart) != 0) {
+                if (restart_v)
+                    for (int i = a; i < (NS >> 2); i += 32) reinterpret_cast<uint4*>(vis32)[i] = make_uint4(0, 0, 0, 0);
+            }
+            if (is_pol && !restart_v) vc = (int)atomicAdd(vis32 + pos1_v, 1u) + 1;
         }
-        S3(5)
         // ---- belief: new episode -> prior, reveal -> delta on MrX's node, else one filter step
         if (has_belief) {
             const int node0 = rdlane(pos1_v, 0), node1 = rdlane(pos1_v, 32);
@@ -2715,6 +3029,38 @@ __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap
             bl.step(L, N, P, bf0, bf1, node0, node1, onehot, pol_ev, pol0, pol1, uni, norm_now);
         }
         S3(6)
+        if (POL) {      // rewards of the step (reward_calculator.py:63-90 constants, :94-266 shaped)
+            const int qcnt = a == 0 ? ((meta_v >> kMetaCntShift) & 31) : (int)((uint32_t)w.y >> 16);
+            const bool ended_v = (fl_v & (kFlagTerm | 2)) != 0;
+            const bool cap_v = ((fl_v >> kFlagWinShift) & 3) == 1;
+            double shaped = 0.0;
+            if (do_shaped) shaped = shaped_reward3(tb, a, P, POLM, t0_v, qcnt, vc, dm, dj, kc);
+            rew = ended_v ? (cap_v ? (a == 0 ? -1.0 : 1.0) : (a == 0 ? 1.0 : 0.0)) : shaped;
+            rw_lo = __double2loint(rew);
+            rw_hi = __double2hiint(rew);
+        }
+        // ---- the packed record row of the transition
+        if (REC) {
+            int* rdst = at_bytes(out.record, off_rec);
+            if (store_ok) {
+                if (a < A) {
+                    typedef int v2i __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<v2i*>(rdst + 2 * a) = (v2i){rw_lo, rw_hi};      // the float64 reward
+                    rdst[2 * A + a] = pos0_v;
+                    rdst[3 * A + a] = mon0_v;
+                    rdst[4 * A + a] = act0_v;
+                }
+                if (a < RW - 5 * A)
+                    rdst[5 * A + a] = a == 0 ? t0_v : (a == 1 ? (fl_v & kFlagTerm) : (a == 2 ? ((fl_v >> 1) & 1) : (a == 3 ? ((fl_v >> kFlagWinShift) & 3) : 0)));
+            }
+            out.record += (size_t)B * RW;
+            if (POL && out.log_prob) {
+                if (store_ok && a < A) out.log_prob[(size_t)eh * A + a] = logp0_v;   // of the action executed in this step
+                out.log_prob += (size_t)B * A;
+            }
+        }
+        S3(5)
+        if (POL) logp0_v = __int_as_float(w.z);
         pos0_v = pos1_v;
         act0_v = act1_v;
         mon0_v = mon1_v;
@@ -2722,11 +3068,17 @@ __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap
     }
     S3_DUMP("helper [belief store, wait entry, read+unpack, -, -, record store, belief, loophead]", T)
     if (has_belief) bl.finish(kernarg_params()->st.belief, NS, e, live1, !pol_ev);
+    if (POL && store_ok) {      // the helper's share of the live state when it evaluates the rewards
+        const KernargParams kq = kernarg_params();
+        if (a0 < A) kq->st.reward[(size_t)eh * A + a0] = rew;
+        uint16_t* vis_out = kq->st.visits;
+        for (int i = a0; i < NS; i += 32) vis_out[(size_t)eh * NS + i] = (uint16_t)vis32[i];
+    }
 }
 
 // Block = wpb episodes (even): wpb / 2 move waves, then wpb / 2 helper waves — one wave per episode, 16 episodes
 // per 1024-thread block (one block per CU at B = 4096), 4 waves per SIMD.
-template <int NR, bool REC, int PT>
+template <int NR, bool REC, int PT, bool POL = false>   // POL: actions from the MAPPO actors (sy_env_set_policy)
 __global__ __launch_bounds__(1024, 4) void rollout3_kernel(const EngineParams p, const int T, const sy_rollout_buffers out_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -2750,8 +3102,8 @@ __global__ __launch_bounds__(1024, 4) void rollout3_kernel(const EngineParams p,
     }
     __syncthreads();
     if (e >= B) return;
-    if (helper_role) helper_wave3<NR, REC, PT>(p, L, E, E1, lane, e, g, T, out_arg);
-    else move_wave3<REC, PT>(p, L, E, E1, lane, e, g, T, out_arg);
+    if (helper_role) helper_wave3<NR, REC, PT, POL>(p, L, E, E1, lane, e, g, T, out_arg);
+    else move_wave3<NR, REC, PT, POL>(p, L, E, E1, lane, e, g, slot, T, out_arg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3402,18 +3754,26 @@ static hipError_t launch_engine_nr(const EngineParams& p, const int32_t* actions
         // the move / helper pipeline (rollout3) covers boards whose agents fit one or two scan passes
         const int per_pass = 64 / p.scan_w;
 #ifdef SY_NO_PIPELINE
-        const bool pipelined = false;
+        const bool pipelined = false, pol_pipeline = false;
         const int threads3 = 0;
 #else
         // ... of up to 256 nodes (node-major belief lanes)
         const int threads3 = 64 * wpb;
+#ifdef SY_POL_ROLLOUT2
+        const bool pol_pipeline = false;
+#else
+        const bool pol_pipeline = true;
+#endif
         const bool pipelined = NR <= 4 && p.A <= 2 * per_pass && p.max_t < (1 << 20) - 2;
 #endif
         const int threads = paired ? 64 * (wpb / 2 + (p.st.belief ? wpb / 2 : 0))
                                    : 64 * (wpb + (p.st.belief ? (wpb + 1) / 2 : 0));   // move waves + belief waves
 #define SY_LAUNCH_ROLLOUT(PT_)                                                                                            \
     do {                                                                                                                  \
-        if (paired && p.pw2 != nullptr) {                                                                                 \
+        if (paired && pipelined && pol_pipeline && p.pw2 != nullptr && p.A <= per_pass) {                                 \
+            hipLaunchKernelGGL((rollout3_kernel<(NR <= 4 ? NR : 1), true, (PT_ == 4 ? 4 : 0), true>), dim3(blocks),        \
+                               dim3(threads3), lds + (size_t)wpb * p.pslice, stream, p, T, out);                           \
+        } else if (paired && p.pw2 != nullptr) {                                                                          \
             hipLaunchKernelGGL((rollout2_kernel<NR, true, (PT_ == 4 ? 4 : 0), true>), dim3(blocks), dim3(threads),        \
                                lds + (size_t)wpb * SY_POLICY_SLICE, stream, p, T, out);                                    \
         } else if (paired && pipelined) {                                                                                 \

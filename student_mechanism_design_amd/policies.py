@@ -122,8 +122,9 @@ class DeviceMappoPolicy:
         if self.device.type != "cuda":
             raise _lib.EngineError("DeviceMappoPolicy needs the module on a GPU; there is no CPU fallback")
         self.H = net.actors[0][0].out_features
-        if self.H > 64:
-            raise ValueError("hidden size above 64 is not supported by the fused kernel")
+        if self.H > 128 or self.H % 4:
+            raise ValueError("the fused kernels support hidden sizes that are multiples of 4, up to 128 "
+                             "(sy_mappo_policy_act: up to 64)")
         self.seed = int(seed) & (2**64 - 1)
         self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._out = None
@@ -147,20 +148,35 @@ class DeviceMappoPolicy:
             "c2": self.net.critic[2].weight.reshape(-1),                # [H]
             "cb2": self.net.critic[2].bias,
             "w2": torch.stack([a[2].weight for a in acts]),             # [A, N, H] (torch layout: a node's row contiguous)
+            "logit_bound": self._logit_bound(),                         # [A] (the in-kernel underflow rule's cheap test)
         }
         if getattr(self, "_packed", None) is None:
             self._packed = {k: v.to(**f32).contiguous().clone() for k, v in packed.items()}
             self._w = self._lib_mod.MappoWeights(*[C.c_void_p(self._packed[k].data_ptr()) for k in (
-                "w1t", "b1", "w2t", "b2", "c1t", "cb1", "c2", "cb2", "w2")])
+                "w1t", "b1", "w2t", "b2", "c1t", "cb1", "c2", "cb2", "w2", "logit_bound")])
         else:
             for k, v in packed.items():
                 self._packed[k].copy_(v)
+
+    @torch.no_grad()
+    def _logit_bound(self) -> torch.Tensor:
+        """[A] an upper bound of every logit actor a can produce, whatever the observation: the hidden units are
+        relu(b1 + sum of `hot` columns of W1) (hot = 1: MrX's one-hot input; P: the police actors' multi-hot input), so
+        h_k <= hmax_k = max(b1_k, 0) + hot * max_n max(W1[k, n], 0) and logit_n <= b2_n + sum_k max(W2[n, k], 0) * hmax_k."""
+        out = []
+        for a, actor in enumerate(self.net.actors):
+            hot = 1 if a == 0 else self.net.P
+            hmax = actor[0].bias.clamp_min(0) + hot * actor[0].weight.clamp_min(0).max(dim=1).values     # [H]
+            out.append((actor[2].bias + actor[2].weight.clamp_min(0) @ hmax).max())
+        return torch.stack(out).float()
 
     @torch.no_grad()
     def act(self, obs: Dict[str, torch.Tensor], want_probs: bool = False):
         """Collector callback: (actions int32 [B, A], log_prob [B, A], value [B]); with want_probs a 4th item,
         the actors' softmax [B, A, N].  The first three are persistent buffers, overwritten by the next call."""
         import ctypes as C
+        if self.H > 64:
+            raise ValueError("sy_mappo_policy_act supports hidden sizes up to 64 (the in-kernel policy, env.set_policy, up to 128)")
         pos, mask = obs["agent_position"], obs["action_mask"]
         B, A = pos.shape
         N = self.net.N

@@ -67,16 +67,26 @@ def usable_cores():
     return n
 
 
-def kernel_name(N, P, wpb, record, policy):
+def kernel_name(N, P, wpb, record, policy, max_degree):
     """The instance the launcher picks (csrc/sy_kernels.hip::launch_engine_nr) for this configuration."""
     nr = (N + 63) // 64
     nr = 1 if nr <= 1 else 2 if nr <= 2 else 4 if nr <= 4 else 8 if nr <= 8 else 16
     pt = P if P in (2, 4, 5, 6) else 0
+    A = P + 1
+    md = 16 if (max_degree <= 0 or max_degree > 16) else max(8, max_degree)        # sy_capi.hip::sy_env_set_graph_pool
+    coarse = 8 if md <= 8 else (12 if md <= 12 else 16)
+    scan_w = md if (A > 64 // coarse and 64 // md > 64 // coarse) else coarse
+    rec = "true" if record else "false"
+    if wpb % 2 == 0 and nr <= 4 and A <= 2 * (64 // scan_w):
+        if policy and A <= 64 // scan_w:
+            return f"sy::rollout3_kernel<{nr},true,{4 if pt == 4 else 0},true>", "move / helper pipeline, learned policy in the move wave"
+        if not policy:
+            return f"sy::rollout3_kernel<{nr},{rec},{pt},false>", "move / helper pipeline: paired move waves + helper waves"
     if wpb % 2 == 0:
         if policy:
-            return f"sy::rollout2_kernel<{nr},true,{4 if pt == 4 else 0},true>"
-        return f"sy::rollout2_kernel<{nr},{'true' if record else 'false'},{pt},false>"
-    return f"sy::rollout_kernel<{nr},{'true' if record else 'false'},{pt}>"
+            return f"sy::rollout2_kernel<{nr},true,{4 if pt == 4 else 0},true>", "paired move waves + belief waves"
+        return f"sy::rollout2_kernel<{nr},{rec},{pt},false>", "paired move waves + belief waves"
+    return f"sy::rollout_kernel<{nr},{rec},{pt}>", "one move wave per episode + belief waves"
 
 
 def make_oracle(args, boards, weights, env_graph, threads, env_id_offset=0):
@@ -288,8 +298,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "hbm_frac_measured": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     "kernel": kernel_name(N, P, env.waves_per_block, not args.no_record, False) +
-                     " (fused rollout: paired move waves + belief waves)",
+                     "kernel": "%s (fused rollout: %s)" % kernel_name(N, P, env.waves_per_block, not args.no_record, False, env.max_degree),
                      "kernel_ms": kern_ms, "kernel_ms_min": float(kern.min()), "kernel_ms_max": float(kern.max()),
                      "algorithmic_bytes_per_env_step": R + W, "algorithmic_read_bytes_per_env_step": R,
                      "read_only_frac": (R * T * B / (kern_ms * 1e-3) / 1e9) / HBM_PEAK_GBS,

@@ -6,12 +6,17 @@
 // lookup tables; every episode owns a private LDS slice (mask rows, visit counters, belief scratch,
 // ring).  Kernels:
 //   step_kernel          one transition with caller actions, one wavefront per episode
-//   rollout2_kernel      the fused rollout: a "move" wavefront carries TWO episodes (lanes 0-31 / 32-63,
-//                        per-half predicates as scalar lane masks, DPP pair checks and reductions) and a
-//                        partner "belief" wavefront filters the same two episodes in lockstep, fed through
-//                        a small LDS ring: 4 waves per SIMD at 16 episodes per CU.  Actions come from the
-//                        uniform-random policy or (POL) from the MAPPO actors evaluated in the kernel.
+//   rollout3_kernel      the fused rollout (default): a two-stage pipeline per pair of episodes — a "move"
+//                        wavefront carries TWO episodes (lanes 0-31 / 32-63, per-half predicates as scalar
+//                        lane masks, DPP pair checks and reductions) and runs the state feedback loop plus
+//                        everything that reads the board; a "helper" wavefront takes what only leaves the
+//                        chip (record rows, the belief filter and its rows) from an LDS ring: 4 waves per
+//                        SIMD at 16 episodes per CU.  Actions come from the uniform-random policy or (POL)
+//                        from the MAPPO actors evaluated in the move wave (rewards then move to the helper).
+//   rollout2_kernel      round 1's two-role kernel (move wave does everything but the belief): boards of more
+//                        than 256 nodes / more than two scan passes, A/B baseline
 //   rollout_kernel       the same with one episode per move wave (odd block sizes)
+//   returns_kernel       returns / advantages / GAE of a whole [T][B][A] record in one launch
 //   reset / belief_update / action_mask_dense / apsp / sample_boards        reset-side and standalone ops
 //   masked_sample / mappo_policy      policy side: masked categorical sampling; the MAPPO networks with
 //                        the second layers on the matrix cores (f32 MFMA) — the only GEMM-shaped work here.

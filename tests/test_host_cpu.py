@@ -298,3 +298,13 @@ def test_scripts_compile():
     assert len(files) >= 10
     for f in files:
         py_compile.compile(f, doraise=True, cfile=os.path.join("/tmp", "sy_pyc_" + os.path.basename(f) + "c"))
+
+
+def test_optional_torchrl_registration_is_import_guarded():
+    """the torchrl EnvBase registration is optional.  torchrl / tensordict are absent offline, so the module
+    must import cleanly and `make_torchrl_env` must fail with an ImportError that says what to install (parity unpinned)."""
+    import student_mechanism_design_amd.torchrl_env as t
+    if t.torchrl_available():
+        pytest.skip("torchrl present: the wrapper itself needs a GPU engine to construct")
+    with pytest.raises(ImportError, match="torchrl"):
+        t.make_torchrl_env(None)

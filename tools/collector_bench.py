@@ -24,11 +24,13 @@ from student_mechanism_design_amd.collector import DeviceMaskedSampler  # noqa: 
 smp = DeviceMaskedSampler(env.device, seed=7)
 from student_mechanism_design_amd.policies import DeviceMappoPolicy  # noqa: E402
 fused = DeviceMappoPolicy(pol, seed=7)
+# NOTE (round 2): `probs_fast` (index lookups + baddbmm) replayed from a HIP graph produced a few NaN probabilities per
+# collect on torch 2.10 + ROCm 7.0 (eager runs of the same code never do; cause not found, the engine's tensors were
+# verified clean), and torch.multinomial's device-side assert then aborts the process.  The torch forward is therefore
+# timed with eager launches only; graph replay is timed with the HIP policy kernel, which is capture-safe and tested.
 for use_graph, fn, name in ((False, pol.act, "reference-shaped forward, torch sampling"),
-                            (True, pol.act, "reference-shaped forward, torch sampling"),
-                            (True, pol.act_fast, "lookup + batched-matmul forward, torch sampling"),
+                            (False, pol.act_fast, "lookup + batched-matmul forward, torch sampling"),
                             (False, lambda obs: pol.act_device(obs, smp), "lookup + batched-matmul forward, HIP sampling kernel"),
-                            (True, lambda obs: pol.act_device(obs, smp), "lookup + batched-matmul forward, HIP sampling kernel"),
                             (False, fused.act, "fused HIP policy kernel (actors + sampling + critic)"),
                             (True, fused.act, "fused HIP policy kernel (actors + sampling + critic)")):
     col = RolloutCollector(env, fn, frames_per_batch=T, use_graph=use_graph)

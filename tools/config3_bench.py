@@ -8,8 +8,9 @@ One iteration = collect T steps of B envs + returns/advantages (`sy_returns_adva
 the T*B*(P+1) transitions in minibatches.  Policies:
   gnn      GnnQPolicy (pure-torch AntiSymmetricConv x2 + Linear, greedy masked arg-max) driving the per-step collector;
            update = one TD(0) step of the DQN loss on the collected transitions (gnn_agent.py's update, batched)
-  mappo    MappoPolicy (torch MLP actors + central critic) driving the per-step collector (HIP sampling kernel,
-           HIP-graph replay); update = clipped PPO surrogate + critic MSE (mappo_agent.py:260-293)
+  mappo    MappoPolicy (torch MLP actors + central critic) driving the per-step collector (torch forward, HIP sampling
+           kernel, eager launches); update = clipped PPO surrogate + critic MSE (mappo_agent.py:260-293)
+  kernel   the same networks as ONE HIP policy kernel per step (DeviceMappoPolicy), the T-step loop replayed as a HIP graph
   fused    the same MAPPO networks sampled INSIDE the fused rollout kernel (sy_env_set_policy); same update
 Prints one JSON line per policy: agent-steps/s for collect alone and for the whole iteration, and ms per phase.
 
@@ -83,7 +84,7 @@ def gnn_update(gnn, opt, rec, a_hat_b, N, gamma, minibatch_steps):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--policies", default="gnn,mappo,fused")
+    ap.add_argument("--policies", default="gnn,mappo,kernel,fused")
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--nodes", type=int, default=200)
     ap.add_argument("--police", type=int, default=4)
@@ -111,7 +112,10 @@ def main():
             fused = DeviceMappoPolicy(net, seed=3)
             if name == "mappo":
                 smp = col.DeviceMaskedSampler(dev, seed=7)
-                collector = col.RolloutCollector(env, lambda obs: net.act_device(obs, smp), frames_per_batch=T, use_graph=True)
+                collector = col.RolloutCollector(env, lambda obs: net.act_device(obs, smp), frames_per_batch=T)
+                collect = collector.collect
+            elif name == "kernel":
+                collector = col.RolloutCollector(env, fused.act, frames_per_batch=T, use_graph=True)
                 collect = collector.collect
             else:
                 env.set_policy(fused)

@@ -50,6 +50,12 @@ static constexpr int kRing = SY_RING;          // move wave -> belief wave ring 
 #endif
 static constexpr int kSpinMax = SY_SPIN_MAX;   // every spin is bounded: a lost partner cannot hang the GPU
 
+#ifdef SY_ISA_ONLY   // way-points for tools/isa_hot.py (comments in the assembly listing of the ISA-only build)
+#define SY_HOT(tag) asm volatile("; SYHOT " #tag)
+#else
+#define SY_HOT(tag)
+#endif
+
 __device__ __forceinline__ void wave_lds_fence() {
     // LDS operations of one wave execute in order; this only stops the compiler from reordering
     // the cross-lane LDS hand-offs inside a wave.
@@ -78,6 +84,14 @@ static constexpr uint64_t kLowHalf = 0x00000000ffffffffull, kHighHalf = 0xffffff
 __device__ __forceinline__ uint64_t half_any(uint64_t m) {      // each half all-ones iff any of its bits is set
     const uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
     const uint32_t mlo = lo ? ~0u : 0u, mhi = hi ? ~0u : 0u;
+    return ((uint64_t)mhi << 32) | mlo;
+}
+// The same for masks of agent lanes (bits 0..7 of a half; any value below 2^31 works) in plain scalar arithmetic: the
+// compare-and-select form above makes the compiler route the booleans through the vector unit.
+__device__ __forceinline__ uint32_t nz31(uint32_t m) { return (0u - m) >> 31; }   // 1 iff m != 0   (m < 2^31)
+__device__ __forceinline__ uint32_t z31(uint32_t m) { return (m - 1u) >> 31; }    // 1 iff m == 0   (m < 2^31)
+__device__ __forceinline__ uint64_t half_any8(uint64_t m) {
+    const uint32_t mlo = 0u - nz31((uint32_t)m), mhi = 0u - nz31((uint32_t)(m >> 32));
     return ((uint64_t)mhi << 32) | mlo;
 }
 __device__ __forceinline__ uint64_t half_pick(uint64_t lo_src, uint64_t hi_src) {
@@ -1443,6 +1457,7 @@ __device__ __forceinline__ PairScanLane make_pair_scan_lane(const EnvLds& E, con
 template <bool BEGIN = true, bool END = true>
 __device__ __forceinline__ void scan_eval_pair1(PairScanLane& q, const ScanMap& sm, int gw, const ScanPairIn& g, int& act_v,
                                                 int& cost_v, int& quirk_cnt) {
+    SY_HOT(m_eval);
     if (BEGIN && lanes(kAgentSlots)) *lds_at<uint64_t>(q.selr) = 0x0000ffffull;   // "no move": action -1, cost 0
     *lds_at<uint8_t>(q.prev0) = 0;
     *lds_at<uint8_t>(q.prev1) = 0;
@@ -1966,6 +1981,7 @@ __device__ __forceinline__ double shaped_reward3(const RewardTabs& tb, int a, in
     int overlap = 0;
     if (bal(dor >= kLdsTab) == 0ull) {
         // fast path (wave-uniform): every lookup hits the LDS tables, all reads issued back to back
+        SY_HOT(m_rew_fast);
         xa = lds_f64(tb.nrc_s + mn);     // lanes past the agents read out of range: LDS returns garbage or 0, unused
         xb = lds_f64(tb.nra_s + sum);
         e_mrx = lds_f64(tb.exp_s + dm);
@@ -2172,6 +2188,7 @@ __global__ __launch_bounds__(1024, 4) void rollout2_kernel(const EngineParams p,
         if (5 < P) CF |= pair_conflicts<5>(tgt_v, pos_v) & (POLM & (POLM << 5));
         if (6 < P) CF |= pair_conflicts<6>(tgt_v, pos_v) & (POLM & (POLM << 6));
         if (CF == 0ull) {                              // no police collision in either episode: order cannot matter
+            SY_HOT(m_moves);
             const uint64_t mv = POLM & ~SK & bal(tgt_v != pos_v);
             pos_v = lanes(mv) ? tgt_v : pos_v;
             mon_v -= lanes(mv) ? cost_v : 0;                                  // :234-236
@@ -2458,12 +2475,13 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
     float logp_v = 0.0f;
     if (POL) pll = make_pol_lane3(p, sm, lane, A, pol0, pol1);
     int rev_v = p.reveal_k > 0 ? p.reveal_k - (t_v % p.reveal_k) : 0;
+    // the draws of a Philox block are used one per step: xw[0] is always the word of the coming step (the words are
+    // shifted down after every step instead of being selected by the step count)
     uint32_t xw[4];
     philox4(gid, sc_v >> 2, kPurposeAct, (uint32_t)a0, p.seed_lo, p.seed_hi, xw);
-    auto draw_word = [&xw](uint32_t c) {
-        const uint32_t m = c & 3u;
-        return m == 0 ? xw[0] : (m == 1 ? xw[1] : (m == 2 ? xw[2] : xw[3]));
-    };
+#pragma unroll
+    for (uint32_t r = 1; r <= 3; ++r)
+        if ((sc_v & 3u) >= r) { xw[0] = xw[1]; xw[1] = xw[2]; xw[2] = xw[3]; }
     rec_h[a0] = 0;
     rec_h[32 + a0] = 0;
     for (int i = lane; i < n16; i += kWave) {
@@ -2476,7 +2494,7 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
     if (!one_pass) psl2 = make_pair_scan_lane(E, E1, sm, lane, A, NS, sm.per_pass);
     int act_v = -1, cost_v = 0, qcnt = 0;
     {
-        const ScanPairIn g0 = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, draw_word(sc_v));
+        const ScanPairIn g0 = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, xw[0]);
         if (POL) {           // (the launcher only picks this instance for single-pass boards)
             policy_hidden_pair3(p, P, A, pos_v, lane, pol0, pol1);
             wave_lds_fence();
@@ -2484,7 +2502,7 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         } else if (one_pass) {
             scan_eval_pair1(psl, sm, p.scan_w, g0, act_v, cost_v, qcnt);
         } else {
-            const ScanPairIn g1 = scan_gather_pair(L.ell_s, A, sm, sm.per_pass, pos_v, mon_v, draw_word(sc_v));
+            const ScanPairIn g1 = scan_gather_pair(L.ell_s, A, sm, sm.per_pass, pos_v, mon_v, xw[0]);
             scan_eval_pair1<true, false>(psl, sm, p.scan_w, g0, act_v, cost_v, qcnt);
             scan_eval_pair1<false, true>(psl2, sm, p.scan_w, g1, act_v, cost_v, qcnt);
         }
@@ -2525,7 +2543,8 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
     double rew = 0.0;
     int term_v = 0, trunc_v = 0, win_v = 0;
     const uint64_t POLM = (((1ull << P) - 1ull) << 1) * 0x0000000100000001ull;   // police lanes of both halves
-    constexpr uint64_t kMrxLanes = 0x0000000100000001ull;
+    const uint32_t POL32 = (uint32_t)POLM;                                       // ... of one half
+
 
     S3_DECL
     for (int s = 0; s < T; ++s) {
@@ -2541,8 +2560,9 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         const uint64_t SK = bal(act_v == -1) | bal(mon_v == 0);               // skipped agents (:210-215)
         {   // MrX vs PRE-move police (:180-188)
             const int t_lo = rdlane(tgt_v, 0), t_hi = rdlane(tgt_v, 32);
-            const uint64_t hit = half_pick(bal(pos_v == t_lo), bal(pos_v == t_hi)) & POLM;
-            pos_v = lanes(kMrxLanes & ~half_any(hit)) ? tgt_v : pos_v;
+            const uint32_t hit_lo = (uint32_t)bal(pos_v == t_lo) & POL32, hit_hi = (uint32_t)(bal(pos_v == t_hi) >> 32) & POL32;
+            const uint64_t mrx_moves = (uint64_t)z31(hit_lo) | ((uint64_t)z31(hit_hi) << 32);   // lanes 0 / 32
+            pos_v = lanes(mrx_moves) ? tgt_v : pos_v;
         }
         uint64_t CF = 0;   // any police pair that could interact this step?
         if (1 < P) CF |= pair_conflicts<1>(tgt_v, pos_v) & (POLM & (POLM << 1));
@@ -2552,6 +2572,7 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         if (5 < P) CF |= pair_conflicts<5>(tgt_v, pos_v) & (POLM & (POLM << 5));
         if (6 < P) CF |= pair_conflicts<6>(tgt_v, pos_v) & (POLM & (POLM << 6));
         if (CF == 0ull) {                              // no police collision in either episode: order cannot matter
+            SY_HOT(m_moves);
             const uint64_t mv = POLM & ~SK & bal(tgt_v != pos_v);
             pos_v = lanes(mv) ? tgt_v : pos_v;
             mon_v -= lanes(mv) ? cost_v : 0;                                  // :234-236
@@ -2566,9 +2587,9 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
                 }
             }
         }
-        const uint64_t NM = ~half_any(POLM & ~SK);                            // nobody could act (:191,216)
+        const uint64_t NM = ~half_any8(POLM & ~SK);                           // nobody could act (:191,216)
         // ---- outcome priority (reward_calculator.py:63-90)
-        const uint64_t CAP = half_any(half_pick(bal(pos_v == rdlane(pos_v, 0)), bal(pos_v == rdlane(pos_v, 32))) & POLM);
+        const uint64_t CAP = half_any8(half_pick(bal(pos_v == rdlane(pos_v, 0)), bal(pos_v == rdlane(pos_v, 32))) & POLM);
         const uint64_t TO = bal(t_v > p.max_t);                               // t_v is replicated over its half
         const uint64_t ENDED = CAP | TO | NM;
         const uint64_t NEED = p.auto_reset != 0 ? ENDED : 0ull;
@@ -2598,13 +2619,16 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         S3(1)
         // ---- next step's draw and the gather half of the scan of the new state
         const uint32_t nxt_v = sc_v + 1u;
-        if (bal((nxt_v & 3u) == 0u) != 0ull) {
+        if (bal((nxt_v & 3u) == 0u) != 0ull) {      // some episode starts a new block (the two of a pair may be out of phase)
             uint32_t nw[4];
             philox4(gid, nxt_v >> 2, kPurposeAct, (uint32_t)a, p.seed_lo, p.seed_hi, nw);
-            if ((nxt_v & 3u) == 0u) { xw[0] = nw[0]; xw[1] = nw[1]; xw[2] = nw[2]; xw[3] = nw[3]; }
+            const bool refill = (nxt_v & 3u) == 0u;
+            xw[0] = refill ? nw[0] : xw[1]; xw[1] = refill ? nw[1] : xw[2]; xw[2] = refill ? nw[2] : xw[3]; xw[3] = refill ? nw[3] : xw[3];
+        } else {
+            xw[0] = xw[1]; xw[1] = xw[2]; xw[2] = xw[3];
         }
         sc_v = nxt_v;
-        const uint32_t x_next = draw_word(nxt_v);
+        const uint32_t x_next = xw[0];
         const ScanPairIn sg = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, x_next);
         ScanPairIn sg2 = sg;
         if (!one_pass) sg2 = scan_gather_pair(L.ell_s, A, sm, sm.per_pass, pos_v, mon_v, x_next);
@@ -2618,6 +2642,7 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
 #pragma unroll
         for (int j = 1; j < SY_MAX_AGENTS; ++j) dj[j - 1] = 0;
         if (!POL) {
+            SY_HOT(m_visits);
             if (is_pol) vc = (int)atomicAdd(vis32 + pos_m, 1u) + 1;
             if (NEED != 0ull) {                // a new episode starts from zero (yard.py:85)
                 if (lanes(NEED))
@@ -2644,6 +2669,7 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
             typedef unsigned int v4u __attribute__((ext_vector_type(4)));
             const v4u v0 = *lds_at<v4u>(mc_lds0), v1 = *lds_at<v4u>(mc_lds1), v2 = *lds_at<v4u>(mc_lds2);
             if (store_ok) {
+                SY_HOT(m_maskcopy);
                 *reinterpret_cast<v4u*>(out.mask + mc_off0) = v0;
                 *reinterpret_cast<v4u*>(out.mask + mc_off1) = v1;
                 *reinterpret_cast<v4u*>(out.mask + mc_off2) = v2;
@@ -2668,6 +2694,7 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         S3(4)
         // ---- rewards of the step (reward_calculator.py:63-90 constants, :94-266 shaped)
         if (!POL) {
+            SY_HOT(m_rewards);
             const double shaped = shaped_reward3(tb, a, P, POLM, t_rew, qcnt, vc, dm, dj, kc);
             rew = lanes(ENDED) ? (lanes(CAP) ? (a == 0 ? -1.0 : 1.0) : (a == 0 ? 1.0 : 0.0)) : shaped;
         }
@@ -2786,6 +2813,7 @@ struct BeliefLanes {
                                          const int (&pol0)[SY_MAX_AGENTS - 1], const int (&pol1)[SY_MAX_AGENTS - 1], float uni,
                                          bool norm_now) {
         if (bf0 == 0 || bf1 == 0) {
+            SY_HOT(h_belstep);
             if (mine) {      // c = b / deg of my nodes: NR * 8 contiguous bytes of the interleaved scratch
                 if (NR == 1) {
                     *lds_at<v2f>(c_mine) = b[0] * ideg[0];
@@ -2963,6 +2991,7 @@ __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap
         }
 #endif
         if (rec_bel) {      // the belief before the step goes to the record
+            SY_HOT(h_belrec);
             bl.record(out.belief, NS, live1);
             out.belief += bel_step;
         }
@@ -3048,6 +3077,7 @@ __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap
         if (REC) {
             int* rdst = at_bytes(out.record, off_rec);
             if (store_ok) {
+                SY_HOT(h_row);
                 if (a < A) {
                     typedef int v2i __attribute__((ext_vector_type(2)));
                     *reinterpret_cast<v2i*>(rdst + 2 * a) = (v2i){rw_lo, rw_hi};      // the float64 reward
@@ -3752,6 +3782,10 @@ __global__ __launch_bounds__(256) void returns_kernel(const ReturnsArgs a) {
 template <int NR>
 static hipError_t launch_engine_nr(const EngineParams& p, const int32_t* actions, int T, const sy_rollout_buffers& out,
                                    bool ext, int blocks, int wpb, size_t lds, hipStream_t stream) {
+#ifdef SY_ISA_ONLY   // tools/isa_only.sh: only the headline instance, for a quick look at its ISA (not a usable library)
+    if (NR == 4) hipLaunchKernelGGL((rollout3_kernel<4, true, 4>), dim3(blocks), dim3(64 * wpb), lds, stream, p, T, out);
+    return hipGetLastError();
+#else
     if (ext) {
         hipLaunchKernelGGL((step_kernel<NR>), dim3(blocks), dim3(wpb * 64), lds, stream, p, actions, out);
     } else {
@@ -3806,6 +3840,7 @@ static hipError_t launch_engine_nr(const EngineParams& p, const int32_t* actions
 #undef SY_LAUNCH_ROLLOUT
     }
     return hipGetLastError();
+#endif
 }
 
 hipError_t launch_engine(const EngineParams& p, const int32_t* actions, int T, const sy_rollout_buffers& out, bool ext,

@@ -76,6 +76,7 @@ int sy_env_create(const sy_env_config* c, sy_env** out) {
     p.wave_lds_bytes = p.A * p.NS + p.NS * 4 + (p.NS + 16) * 8 + SY_RING * SY_RING_ENTRY_BYTES + 16 + 256;
     p.rec_words = sy_record_words(p.A);
     p.scan_w = 16;
+    p.max_deg = 16;
     // per-block LDS: board ELL (64 B/node) + belief gather offsets (32 B/node) + reward tables
     const size_t ell_bytes = (size_t)p.N * SY_ELL_WIDTH * 6 + (size_t)(4 * SY_LDS_TABLE + 4 + SY_LDS_AVGTAB + 16) * sizeof(double);
     // The paired rollout kernel runs one wave per episode (a move wave and a belief wave per two episodes),
@@ -135,6 +136,7 @@ int sy_env_set_graph_pool(sy_env* env, const uint32_t* ell, const uint16_t* apsp
     // 6 agents up to rows of 10); instances for at most 5 agents therefore only ever see 8 / 12 / 16
     {
         const int md = (max_degree <= 0 || max_degree > 16) ? 16 : (max_degree < 8 ? 8 : max_degree);
+        env->p.max_deg = (max_degree <= 0 || max_degree > 16) ? 16 : max_degree;
         const int coarse = md <= 8 ? 8 : (md <= 12 ? 12 : 16);
         env->p.scan_w = (env->p.A > 64 / coarse && 64 / md > 64 / coarse) ? md : coarse;
     }

@@ -19,6 +19,7 @@ struct EngineParams {
     int32_t money0, max_t, reveal_k, police_ev, belief_onehot, auto_reset;
     int32_t wave_lds_bytes;       // private LDS slice per episode (mask rows, visits, belief scratch, ring, sync)
     int32_t scan_w;               // ELL columns scanned per agent: 8..16 (>= widest row of the pool)
+    int32_t max_deg;              // widest ELL row of the pool (16 when the caller did not say)
     int32_t rec_words;            // dwords per packed trajectory record (sy_record_words)
     int32_t wpb;                  // episodes (move waves) per launch block
     uint32_t seed_lo, seed_hi;    // Philox key

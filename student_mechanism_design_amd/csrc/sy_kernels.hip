@@ -2433,8 +2433,104 @@ static constexpr int kFlagTerm = 1, kFlagWinShift = 2, kFlagRestart = 16, kFlagR
 #define S3_DUMP(who, T)
 #endif
 
+// ---- the pipeline's neighbour scan for up to 5 agents: one episode per HALF wave ------------------------------
+// The paired scan (scan_eval_pair1) gives every lane one (agent, ELL column) of BOTH episodes: two full instruction
+// streams per lane.  With A <= 5 agents the columns of one episode fit its own half: GW = 32 / A columns per agent
+// (6 at P = 4), lane h*32 + g*GW + c scans columns c and c + GW of agent g of episode h.  The second column is a
+// short second stream (rows wider than GW are rare — 3 % of the visits on reference-shaped 200-node boards — but a
+// quarter of the pair-steps has one, so it is evaluated unconditionally rather than behind a branch); rows wider than
+// 2 GW take the paired scan (the launch-uniform `wide` switch of the move wave).  Counts, the r-th legal neighbour in
+// ascending node order (both columns ranked in one 2 GW-bit field) and the position-reward count are the quantities
+// of scan_sample; results reach the agent lanes through the LDS slots of the paired scan.
+template <int GW>
+struct HalfScan {
+    static constexpr bool kTwo = GW < kD;                          // a second column exists
+    static constexpr uint32_t kField = GW >= 32 ? 0xffffffffu : (1u << GW) - 1u;
+    uint32_t row, selw, selr, scratch, prev0, prev1, low0, low1, bsrc, bsrcq, ell_col;
+    int gsh;
+    bool has1;                                                     // my second column lies inside the ELL row
+    uint64_t on_m, lead_m;
+    struct In { uint32_t ent, ent1, xa; int ma, mq; };
+
+    __device__ __forceinline__ void init(const LdsMap& L, const EnvLds& E, const EnvLds& E1, int lane, int A, int NS) {
+        const bool up = lane >= 32;
+        const int li = lane & 31, grp = li / GW, col = li - grp * GW;
+        const bool on = grp < A;
+        const int ag = on ? grp : 0;
+        const uint32_t rec_h = lds_off(up ? E1.rec_s : E.rec_s);
+        row = lds_off(up ? E1.mrow : E.mrow) + (uint32_t)(ag * NS);
+        selw = rec_h + (uint32_t)(kSelWord + 2 * ag) * 4u;
+        selr = rec_h + (uint32_t)(kSelWord + 2 * (lane & 7)) * 4u;
+        scratch = rec_h + kDummyWord * 4u;
+        prev0 = prev1 = scratch;
+        low0 = (1u << col) - 1u;                                   // entries of my agent ranked before my first column ...
+        low1 = kField | (low0 << GW);                              // ... and before my second one
+        has1 = kTwo && col + GW < kD;
+        gsh = (lane & 32) + ag * GW;
+        bsrc = (uint32_t)((lane & 32) + ag) * 4u;
+        bsrcq = (uint32_t)((lane & 32) + (ag > 0 ? ag - 1 : 0)) * 4u;   // the PREVIOUS agent's budget (reward_calculator.py:190)
+        ell_col = lds_off(L.ell_s) + (uint32_t)col * 4u;
+        on_m = bal(on);
+        lead_m = bal(on && col == 0);
+    }
+    // gather half: the agent's node, budgets and draw by bpermute, then my two columns of the ELL row
+    __device__ __forceinline__ In gather(int pos_v, int mon_v, uint32_t x_v) const {
+        In g;
+        const int pa = bperm((int)bsrc, pos_v);
+        g.ma = bperm((int)bsrc, mon_v);
+        g.mq = bperm((int)bsrcq, mon_v);
+        g.xa = (uint32_t)bperm((int)bsrc, (int)x_v);
+        const uint32_t rowaddr = ell_col + ((uint32_t)pa << 6);
+        g.ent = *lds_at<uint32_t>(rowaddr);
+        g.ent1 = 0xffff0000u;                                      // (a padding entry: never affordable)
+        if (kTwo) {
+            const uint32_t e1 = *lds_at<uint32_t>(rowaddr + (has1 ? (uint32_t)GW * 4u : 0u));
+            g.ent1 = has1 ? e1 : 0xffff0000u;
+        }
+        return g;
+    }
+    // evaluate half: mask bytes of the new state, the next action (uniform over the legal neighbours) and the counts
+    __device__ __forceinline__ void eval(const In& g, int& act_v, int& cost_v, int& quirk_cnt) {
+        SY_HOT(m_eval);
+        if (lanes(kAgentSlots)) *lds_at<uint64_t>(selr) = 0x0000ffffull;   // "no move": action -1, cost 0, count 0
+        *lds_at<uint8_t>(prev0) = 0;
+        if (kTwo) *lds_at<uint8_t>(prev1) = 0;
+        const int w0 = (int)(g.ent >> 16), w1 = (int)(g.ent1 >> 16);
+        const uint64_t bo0 = bal(w0 <= g.ma) & on_m, bq0 = bal(w0 <= g.mq) & on_m;
+        uint32_t gf = (uint32_t)(bo0 >> gsh) & kField, qf = (uint32_t)(bq0 >> gsh) & kField;
+        uint64_t bo1 = 0ull;
+        if (kTwo) {
+            bo1 = bal(w1 <= g.ma) & on_m;
+            const uint64_t bq1 = bal(w1 <= g.mq) & on_m;
+            gf |= ((uint32_t)(bo1 >> gsh) & kField) << GW;
+            qf |= ((uint32_t)(bq1 >> gsh) & kField) << GW;
+        }
+        const int rr = (int)__umulhi(g.xa, (uint32_t)__popc(gf));
+        // lanes without an affordable entry write the scratch word instead of being masked off
+        const uint32_t n0 = lanes(bo0) ? row + (g.ent & 0xffffu) : scratch;
+        *lds_at<uint8_t>(n0) = 1;
+        prev0 = n0;
+        const uint64_t ch0 = bal((int)__popc(gf & low0) == rr) & bo0;
+        *lds_at<int>(lanes(ch0) ? selw : scratch) = (int)g.ent;
+        if (kTwo) {
+            const uint32_t n1 = lanes(bo1) ? row + (g.ent1 & 0xffffu) : scratch;
+            *lds_at<uint8_t>(n1) = 1;
+            prev1 = n1;
+            const uint64_t ch1 = bal((int)__popc(gf & low1) == rr) & bo1;
+            *lds_at<int>(lanes(ch1) ? selw : scratch) = (int)g.ent1;
+        }
+        if (lanes(lead_m)) lds_at<int>(selw)[1] = __popc(qf);
+        wave_lds_fence();
+        const uint64_t r = *lds_at<uint64_t>(selr);
+        act_v = (int)(int16_t)(uint32_t)r;              // 0xffff -> -1
+        cost_v = (int)(((uint32_t)r) >> 16);
+        quirk_cnt = (int)(r >> 32);
+        wave_lds_fence();
+    }
+};
+
 // ---- the move wave -----------------------------------------------------------------------------
-template <int NR, bool REC, int PT, bool POL>
+template <int NR, bool REC, int PT, bool POL, bool HS>   // HS: half-wave neighbour scan (no row of the pool wider than 2 GW)
 __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& L, const EnvLds& E, const EnvLds& E1, int lane, int e,
                                            int g, int slot, int T, sy_rollout_buffers out) {
     const int P = PT > 0 ? PT : p.P, A = P + 1;
@@ -2489,11 +2585,19 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         reinterpret_cast<uint4*>(E1.mrow)[i] = make_uint4(0, 0, 0, 0);
     }
     wave_lds_fence();
+    // up to 5 agents, random policy (police count fixed at compile time): one episode per half wave in the scan
+    constexpr bool HALF = HS && !POL && PT >= 1 && PT <= 4;
+    constexpr int GWH = HALF ? (32 / (PT + 1) > kD ? kD : 32 / (PT + 1)) : kD;
+    HalfScan<GWH> hs;
+    if (HALF) hs.init(L, E, E1, lane, A, NS);
     PairScanLane psl = make_pair_scan_lane(E, E1, sm, lane, A, NS);
     PairScanLane psl2 = psl;
     if (!one_pass) psl2 = make_pair_scan_lane(E, E1, sm, lane, A, NS, sm.per_pass);
     int act_v = -1, cost_v = 0, qcnt = 0;
-    {
+    if (HALF) {
+        const auto g0 = hs.gather(pos_v, mon_v, xw[0]);
+        hs.eval(g0, act_v, cost_v, qcnt);
+    } else {
         const ScanPairIn g0 = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, xw[0]);
         if (POL) {           // (the launcher only picks this instance for single-pass boards)
             policy_hidden_pair3(p, P, A, pos_v, lane, pol0, pol1);
@@ -2629,9 +2733,15 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         }
         sc_v = nxt_v;
         const uint32_t x_next = xw[0];
-        const ScanPairIn sg = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, x_next);
-        ScanPairIn sg2 = sg;
-        if (!one_pass) sg2 = scan_gather_pair(L.ell_s, A, sm, sm.per_pass, pos_v, mon_v, x_next);
+        typename HalfScan<GWH>::In hg;
+        ScanPairIn sg, sg2;
+        if (HALF) {
+            hg = hs.gather(pos_v, mon_v, x_next);
+        } else {
+            sg = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, x_next);
+            sg2 = sg;
+            if (!one_pass) sg2 = scan_gather_pair(L.ell_s, A, sm, sm.per_pass, pos_v, mon_v, x_next);
+        }
         if (POL) policy_hidden_pair3(p, P, A, pos_v, ln, pol0, pol1);      // hidden vectors of the next observation
         S3(2)
         // ---- node_visit_counts (yard.py:244-245), then every agent's post-move node to every lane of its half through
@@ -2683,7 +2793,9 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         }
         S3(3)
         // ---- evaluate half of the scan: masks of the new state, position-reward counts, next action
-        if (POL) {
+        if (HALF) {
+            hs.eval(hg, act_v, cost_v, qcnt);
+        } else if (POL) {
             scan_eval_pair_policy3<NR>(psl, pll, sm, p.scan_w, p.pH, N, ln, p.pw2, p.pb2, sg, act_v, cost_v, qcnt, logp_v);
         } else if (one_pass) {
             scan_eval_pair1(psl, sm, p.scan_w, sg, act_v, cost_v, qcnt);
@@ -2950,11 +3062,15 @@ __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap
 
     typedef int v4i __attribute__((ext_vector_type(4)));
     auto wait_entry = [&](int k) {      // entries 0 .. k are published once produced > k
-        int spin = 0;
-        for (; lds_peek(E.sync) <= k && spin < kSpinMax; ++spin) __builtin_amdgcn_s_sleep(1);
-        if (spin == kSpinMax) report_status(SY_STATUS_BELIEF_WAIT_EXPIRED);
+        if (lds_peek(E.sync) <= k) {    // (usually there already: the bounded wait stays off the common path)
+            int spin = 0;
+            for (; lds_peek(E.sync) <= k && spin < kSpinMax; ++spin) __builtin_amdgcn_s_sleep(1);
+            if (spin == kSpinMax) report_status(SY_STATUS_BELIEF_WAIT_EXPIRED);
+        }
         asm volatile("" ::: "memory");
     };
+    // the outcome words of a record row {t, terminated, truncated, winner, 0 ...}: lane a takes (marks >> shift) & mask
+    const int mw_shift = a0 == 2 ? 1 : (a0 == 3 ? kFlagWinShift : 0), mw_mask = (a0 == 1 || a0 == 2) ? 1 : (a0 == 3 ? 3 : 0);
 
     int pos0_v, act0_v, mon0_v, t0_v;
     {
@@ -3086,7 +3202,7 @@ __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap
                     rdst[4 * A + a] = act0_v;
                 }
                 if (a < RW - 5 * A)
-                    rdst[5 * A + a] = a == 0 ? t0_v : (a == 1 ? (fl_v & kFlagTerm) : (a == 2 ? ((fl_v >> 1) & 1) : (a == 3 ? ((fl_v >> kFlagWinShift) & 3) : 0)));
+                    rdst[5 * A + a] = a == 0 ? t0_v : ((fl_v >> mw_shift) & mw_mask);
             }
             out.record += (size_t)B * RW;
             if (POL && out.log_prob) {
@@ -3113,7 +3229,7 @@ __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap
 
 // Block = wpb episodes (even): wpb / 2 move waves, then wpb / 2 helper waves — one wave per episode, 16 episodes
 // per 1024-thread block (one block per CU at B = 4096), 4 waves per SIMD.
-template <int NR, bool REC, int PT, bool POL = false>   // POL: actions from the MAPPO actors (sy_env_set_policy)
+template <int NR, bool REC, int PT, bool POL = false, bool HS = false>   // POL: actions from the MAPPO actors (sy_env_set_policy); HS: half-wave scan
 __global__ __launch_bounds__(1024, 4) void rollout3_kernel(const EngineParams p, const int T, const sy_rollout_buffers out_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -3138,7 +3254,7 @@ __global__ __launch_bounds__(1024, 4) void rollout3_kernel(const EngineParams p,
     __syncthreads();
     if (e >= B) return;
     if (helper_role) helper_wave3<NR, REC, PT, POL>(p, L, E, E1, lane, e, g, T, out_arg);
-    else move_wave3<NR, REC, PT, POL>(p, L, E, E1, lane, e, g, slot, T, out_arg);
+    else move_wave3<NR, REC, PT, POL, HS>(p, L, E, E1, lane, e, g, slot, T, out_arg);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3783,7 +3899,7 @@ template <int NR>
 static hipError_t launch_engine_nr(const EngineParams& p, const int32_t* actions, int T, const sy_rollout_buffers& out,
                                    bool ext, int blocks, int wpb, size_t lds, hipStream_t stream) {
 #ifdef SY_ISA_ONLY   // tools/isa_only.sh: only the headline instance, for a quick look at its ISA (not a usable library)
-    if (NR == 4) hipLaunchKernelGGL((rollout3_kernel<4, true, 4>), dim3(blocks), dim3(64 * wpb), lds, stream, p, T, out);
+    if (NR == 4) hipLaunchKernelGGL((rollout3_kernel<4, true, 4, false, true>), dim3(blocks), dim3(64 * wpb), lds, stream, p, T, out);
     return hipGetLastError();
 #else
     if (ext) {
@@ -3815,6 +3931,12 @@ static hipError_t launch_engine_nr(const EngineParams& p, const int32_t* actions
         } else if (paired && p.pw2 != nullptr) {                                                                          \
             hipLaunchKernelGGL((rollout2_kernel<NR, true, (PT_ == 4 ? 4 : 0), true>), dim3(blocks), dim3(threads),        \
                                lds + (size_t)wpb * SY_POLICY_SLICE, stream, p, T, out);                                    \
+        } else if (paired && pipelined && PT_ >= 1 && PT_ <= 4 && p.max_deg <= 2 * (32 / (PT_ + 1))) {                     \
+            /* up to 5 agents and no row wider than two columns per scan lane: the half-wave scan */                      \
+            if (out.record)                                                                                               \
+                hipLaunchKernelGGL((rollout3_kernel<(NR <= 4 ? NR : 1), true, (PT_ >= 1 && PT_ <= 4 ? PT_ : 1), false, true>), dim3(blocks), dim3(threads3), lds, stream, p, T, out);\
+            else                                                                                                          \
+                hipLaunchKernelGGL((rollout3_kernel<(NR <= 4 ? NR : 1), false, (PT_ >= 1 && PT_ <= 4 ? PT_ : 1), false, true>), dim3(blocks), dim3(threads3), lds, stream, p, T, out);\
         } else if (paired && pipelined) {                                                                                 \
             if (out.record)                                                                                               \
                 hipLaunchKernelGGL((rollout3_kernel<(NR <= 4 ? NR : 1), true, PT_>), dim3(blocks), dim3(threads3), lds, stream, p, T, out);\

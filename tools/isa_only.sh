@@ -3,7 +3,7 @@
 mkdir -p /tmp/isa && cd "$(dirname "$0")/.."
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off --cuda-device-only -S -DSY_ISA_ONLY "$@" -Iinclude \
   student_mechanism_design_amd/csrc/sy_kernels.hip -o /tmp/isa/fast_all.s 2>&1 | grep -i "error" 
-awk '/^_ZN2sy15rollout3_kernelILi4ELb1ELi4ELb0E.*:/{on=1} on{print} /\.amdhsa_kernel _ZN2sy15rollout3_kernelILi4ELb1ELi4ELb0E/{on=0}' /tmp/isa/fast_all.s \
+awk '/^_ZN2sy15rollout3_kernelILi4ELb1ELi4ELb0ELb1E.*:/{on=1} on{print} /\.amdhsa_kernel _ZN2sy15rollout3_kernelILi4ELb1ELi4ELb0ELb1E/{on=0}' /tmp/isa/fast_all.s \
   | grep -v "^\s*\.\(loc\|cfi\|file\)" | grep -v "^\s*;\s*\(APP\|NO_APP\)" | sed 's/^\s*; SYHOT/SYHOT/' | grep -v "^\s*;" | sed 's/\s*;.*$//' > /tmp/isa/fast.s
 grep -E "vgpr_count|sgpr_count|spill|scratch" /tmp/isa/fast_all.s | grep -i "rollout3\|^\s*;" | head -8
 wc -l /tmp/isa/fast.s

@@ -81,7 +81,10 @@ def kernel_name(N, P, wpb, record, policy, max_degree):
         if policy and A <= 64 // scan_w:
             return f"sy::rollout3_kernel<{nr},true,{4 if pt == 4 else 0},true>", "move / helper pipeline, learned policy in the move wave"
         if not policy:
-            return f"sy::rollout3_kernel<{nr},{rec},{pt},false>", "move / helper pipeline: paired move waves + helper waves"
+            md_exact = 16 if (max_degree <= 0 or max_degree > 16) else max_degree
+            if 1 <= pt <= 4 and md_exact <= 2 * (32 // (pt + 1)):      # the half-wave neighbour scan (launch_engine_nr)
+                return f"sy::rollout3_kernel<{nr},{rec},{pt},false,true>", "move / helper pipeline: paired move waves (half-wave scan) + helper waves"
+            return f"sy::rollout3_kernel<{nr},{rec},{pt},false,false>", "move / helper pipeline: paired move waves + helper waves"
     if wpb % 2 == 0:
         if policy:
             return f"sy::rollout2_kernel<{nr},true,{4 if pt == 4 else 0},true>", "paired move waves + belief waves"

@@ -8,7 +8,8 @@
 //   step_kernel          one transition with caller actions, one wavefront per episode
 //   rollout3_kernel      the fused rollout (default): a two-stage pipeline per pair of episodes — a "move"
 //                        wavefront carries TWO episodes (lanes 0-31 / 32-63, per-half predicates as scalar
-//                        lane masks, DPP pair checks and reductions) and runs the state feedback loop plus
+//                        lane masks, DPP pair checks and reductions; up to 5 agents: the neighbour scan gives each
+//                        episode its own half wave) and runs the state feedback loop plus
 //                        everything that reads the board; a "helper" wavefront takes what only leaves the
 //                        chip (record rows, the belief filter and its rows) from an LDS ring: 4 waves per
 //                        SIMD at 16 episodes per CU.  Actions come from the uniform-random policy or (POL)

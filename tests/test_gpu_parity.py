@@ -196,10 +196,13 @@ def _hub_board(sy, n, hub_degree, rng):
     return sy.make_board(n, np.array(links, dtype=np.int32), w)
 
 
-@pytest.mark.parametrize("police,hub_degree", [(6, 9), (6, 10), (6, 12), (6, 16), (5, 10), (5, 12), (7, 9), (7, 14), (4, 13)])
+@pytest.mark.parametrize("police,hub_degree", [(6, 9), (6, 10), (6, 12), (6, 16), (5, 10), (5, 12), (7, 9), (7, 14), (4, 13),
+                                               (4, 12), (4, 7), (4, 6), (2, 16), (2, 11)])
 def test_fused_rollout_scan_widths_and_passes(sy, ol, police, hub_degree):
     """Every lane mapping of the neighbour scan: exact widths 9 / 10 that save a pass for 6-7 agents, the
-    two-pass slot scan (7 agents at width 12, 6 at 12, 8 at 16), and the generic multi-pass fallback."""
+    two-pass slot scan (7 agents at width 12, 6 at 12, 8 at 16), the generic multi-pass fallback, and the half-wave
+    scan of up to 5 agents (P = 4: 6 columns per agent and lane pair, rows of 6 / 7 / 12 neighbours, 13 falls back to
+    the paired scan; P = 2: 10 columns, rows of 11 and 16)."""
     rng = np.random.default_rng(1000 * police + hub_degree)
     N, B, T = 48, 40, 60
     boards = [_hub_board(sy, N, hub_degree, rng) for _ in range(2)]

@@ -79,12 +79,23 @@ def kernel_name(N, P, wpb, record, policy, max_degree):
     rec = "true" if record else "false"
     if wpb % 2 == 0 and nr <= 4 and A <= 2 * (64 // scan_w):
         if policy and A <= 64 // scan_w:
-            return f"sy::rollout3_kernel<{nr},true,{4 if pt == 4 else 0},true>", "move / helper pipeline, learned policy in the move wave"
+            return f"sy::rollout3_kernel<{nr},true,{4 if pt == 4 else 0},true,0>", "move / helper pipeline, learned policy in the move wave"
         if not policy:
+            # the half-wave neighbour scan (launch_half_scan): columns per scan lane that cover the pool's widest row
             md_exact = 16 if (max_degree <= 0 or max_degree > 16) else max_degree
-            if 1 <= pt <= 4 and md_exact <= 2 * (32 // (pt + 1)):      # the half-wave neighbour scan (launch_engine_nr)
-                return f"sy::rollout3_kernel<{nr},{rec},{pt},false,true>", "move / helper pipeline: paired move waves (half-wave scan) + helper waves"
-            return f"sy::rollout3_kernel<{nr},{rec},{pt},false,false>", "move / helper pipeline: paired move waves + helper waves"
+            gw = min(16, 32 // A)
+            need = (md_exact + gw - 1) // gw
+            cols = need if (A <= 7 and need * gw <= 32) else 0
+            hs = 0
+            if cols > 0 and 1 <= pt <= 4 and cols <= 2:
+                hs = 2
+            elif cols > 0 and nr == 4 and pt in (5, 6):
+                c0 = 2 if pt == 5 else 3
+                hs = c0 if cols <= c0 else (c0 + 1 if cols <= c0 + 1 else 0)
+            if hs:
+                return (f"sy::rollout3_kernel<{nr},{rec},{pt},false,{hs}>",
+                        f"move / helper pipeline: paired move waves (half-wave scan, {hs} columns per lane) + helper waves")
+            return f"sy::rollout3_kernel<{nr},{rec},{pt},false,0>", "move / helper pipeline: paired move waves + helper waves"
     if wpb % 2 == 0:
         if policy:
             return f"sy::rollout2_kernel<{nr},true,{4 if pt == 4 else 0},true>", "paired move waves + belief waves"

@@ -2434,28 +2434,30 @@ static constexpr int kFlagTerm = 1, kFlagWinShift = 2, kFlagRestart = 16, kFlagR
 #define S3_DUMP(who, T)
 #endif
 
-// ---- the pipeline's neighbour scan for up to 5 agents: one episode per HALF wave ------------------------------
+// ---- the pipeline's neighbour scan: one episode per HALF wave ------------------------------------------------------
 // The paired scan (scan_eval_pair1) gives every lane one (agent, ELL column) of BOTH episodes: two full instruction
-// streams per lane.  With A <= 5 agents the columns of one episode fit its own half: GW = 32 / A columns per agent
-// (6 at P = 4), lane h*32 + g*GW + c scans columns c and c + GW of agent g of episode h.  The second column is a
-// short second stream (rows wider than GW are rare — 3 % of the visits on reference-shaped 200-node boards — but a
-// quarter of the pair-steps has one, so it is evaluated unconditionally rather than behind a branch); rows wider than
-// 2 GW take the paired scan (the launch-uniform `wide` switch of the move wave).  Counts, the r-th legal neighbour in
-// ascending node order (both columns ranked in one 2 GW-bit field) and the position-reward count are the quantities
-// of scan_sample; results reach the agent lanes through the LDS slots of the paired scan.
-template <int GW>
+// streams per lane, and two passes when the agents do not fit (6 or 7 agents at rows of more than 10 / 9 neighbours).
+// Here the columns of one episode live in its own half: GW = 32 / A columns per agent (6 at P = 4, 5 at P = 5, 4 at
+// P = 6), lane h*32 + g*GW + c scans columns c, c + GW, ... c + (NC-1) GW of agent g of episode h.  Columns beyond the
+// first are short extra streams, evaluated unconditionally (rows wider than GW are rare — 3 % of the visits on
+// reference-shaped 200-node boards — but a quarter of the pair-steps has one: a branch costs more than it saves);
+// NC is the launch's choice (the pool's widest row fits NC * GW).  Counts, the r-th legal neighbour in ascending node
+// order (all columns ranked in one NC*GW-bit field) and the position-reward count are the quantities of scan_sample;
+// results reach the agent lanes through the LDS slots of the paired scan.
+template <int GW, int NC>
 struct HalfScan {
-    static constexpr bool kTwo = GW < kD;                          // a second column exists
-    static constexpr uint32_t kField = GW >= 32 ? 0xffffffffu : (1u << GW) - 1u;
-    uint32_t row, selw, selr, scratch, prev0, prev1, low0, low1, bsrc, bsrcq, ell_col;
-    int gsh;
-    bool has1;                                                     // my second column lies inside the ELL row
+    static_assert(GW * NC <= 32, "one rank field per agent");
+    static constexpr uint32_t kField = (1u << GW) - 1u;
+    uint32_t row, selw, selr, scratch, low0, bsrc, bsrcq, ell_col;
+    uint32_t prev[NC];
+    int gsh, col;
     uint64_t on_m, lead_m;
-    struct In { uint32_t ent, ent1, xa; int ma, mq; };
+    struct In { uint32_t ent[NC]; uint32_t xa; int ma, mq; };
 
     __device__ __forceinline__ void init(const LdsMap& L, const EnvLds& E, const EnvLds& E1, int lane, int A, int NS) {
         const bool up = lane >= 32;
-        const int li = lane & 31, grp = li / GW, col = li - grp * GW;
+        const int li = lane & 31, grp = li / GW;
+        col = li - grp * GW;
         const bool on = grp < A;
         const int ag = on ? grp : 0;
         const uint32_t rec_h = lds_off(up ? E1.rec_s : E.rec_s);
@@ -2463,10 +2465,9 @@ struct HalfScan {
         selw = rec_h + (uint32_t)(kSelWord + 2 * ag) * 4u;
         selr = rec_h + (uint32_t)(kSelWord + 2 * (lane & 7)) * 4u;
         scratch = rec_h + kDummyWord * 4u;
-        prev0 = prev1 = scratch;
-        low0 = (1u << col) - 1u;                                   // entries of my agent ranked before my first column ...
-        low1 = kField | (low0 << GW);                              // ... and before my second one
-        has1 = kTwo && col + GW < kD;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) prev[k] = scratch;
+        low0 = (1u << col) - 1u;                                   // entries of my agent ranked before my first column
         gsh = (lane & 32) + ag * GW;
         bsrc = (uint32_t)((lane & 32) + ag) * 4u;
         bsrcq = (uint32_t)((lane & 32) + (ag > 0 ? ag - 1 : 0)) * 4u;   // the PREVIOUS agent's budget (reward_calculator.py:190)
@@ -2474,7 +2475,7 @@ struct HalfScan {
         on_m = bal(on);
         lead_m = bal(on && col == 0);
     }
-    // gather half: the agent's node, budgets and draw by bpermute, then my two columns of the ELL row
+    // gather half: the agent's node, budgets and draw by bpermute, then my columns of the ELL row
     __device__ __forceinline__ In gather(int pos_v, int mon_v, uint32_t x_v) const {
         In g;
         const int pa = bperm((int)bsrc, pos_v);
@@ -2482,11 +2483,12 @@ struct HalfScan {
         g.mq = bperm((int)bsrcq, mon_v);
         g.xa = (uint32_t)bperm((int)bsrc, (int)x_v);
         const uint32_t rowaddr = ell_col + ((uint32_t)pa << 6);
-        g.ent = *lds_at<uint32_t>(rowaddr);
-        g.ent1 = 0xffff0000u;                                      // (a padding entry: never affordable)
-        if (kTwo) {
-            const uint32_t e1 = *lds_at<uint32_t>(rowaddr + (has1 ? (uint32_t)GW * 4u : 0u));
-            g.ent1 = has1 ? e1 : 0xffff0000u;
+        g.ent[0] = *lds_at<uint32_t>(rowaddr);
+#pragma unroll
+        for (int k = 1; k < NC; ++k) {                              // a column past the ELL row reads as padding: never affordable
+            const bool in_row = col + k * GW < kD;
+            const uint32_t e = *lds_at<uint32_t>(rowaddr + (in_row ? (uint32_t)(k * GW) * 4u : 0u));
+            g.ent[k] = in_row ? e : 0xffff0000u;
         }
         return g;
     }
@@ -2494,31 +2496,28 @@ struct HalfScan {
     __device__ __forceinline__ void eval(const In& g, int& act_v, int& cost_v, int& quirk_cnt) {
         SY_HOT(m_eval);
         if (lanes(kAgentSlots)) *lds_at<uint64_t>(selr) = 0x0000ffffull;   // "no move": action -1, cost 0, count 0
-        *lds_at<uint8_t>(prev0) = 0;
-        if (kTwo) *lds_at<uint8_t>(prev1) = 0;
-        const int w0 = (int)(g.ent >> 16), w1 = (int)(g.ent1 >> 16);
-        const uint64_t bo0 = bal(w0 <= g.ma) & on_m, bq0 = bal(w0 <= g.mq) & on_m;
-        uint32_t gf = (uint32_t)(bo0 >> gsh) & kField, qf = (uint32_t)(bq0 >> gsh) & kField;
-        uint64_t bo1 = 0ull;
-        if (kTwo) {
-            bo1 = bal(w1 <= g.ma) & on_m;
-            const uint64_t bq1 = bal(w1 <= g.mq) & on_m;
-            gf |= ((uint32_t)(bo1 >> gsh) & kField) << GW;
-            qf |= ((uint32_t)(bq1 >> gsh) & kField) << GW;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) *lds_at<uint8_t>(prev[k]) = 0;
+        uint64_t bo[NC];
+        uint32_t gf = 0, qf = 0;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int w = (int)(g.ent[k] >> 16);
+            bo[k] = bal(w <= g.ma) & on_m;
+            const uint64_t bq = bal(w <= g.mq) & on_m;
+            gf |= ((uint32_t)(bo[k] >> gsh) & kField) << (k * GW);
+            qf |= ((uint32_t)(bq >> gsh) & kField) << (k * GW);
         }
         const int rr = (int)__umulhi(g.xa, (uint32_t)__popc(gf));
-        // lanes without an affordable entry write the scratch word instead of being masked off
-        const uint32_t n0 = lanes(bo0) ? row + (g.ent & 0xffffu) : scratch;
-        *lds_at<uint8_t>(n0) = 1;
-        prev0 = n0;
-        const uint64_t ch0 = bal((int)__popc(gf & low0) == rr) & bo0;
-        *lds_at<int>(lanes(ch0) ? selw : scratch) = (int)g.ent;
-        if (kTwo) {
-            const uint32_t n1 = lanes(bo1) ? row + (g.ent1 & 0xffffu) : scratch;
-            *lds_at<uint8_t>(n1) = 1;
-            prev1 = n1;
-            const uint64_t ch1 = bal((int)__popc(gf & low1) == rr) & bo1;
-            *lds_at<int>(lanes(ch1) ? selw : scratch) = (int)g.ent1;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            // lanes without an affordable entry write the scratch word instead of being masked off
+            const uint32_t n = lanes(bo[k]) ? row + (g.ent[k] & 0xffffu) : scratch;
+            *lds_at<uint8_t>(n) = 1;
+            prev[k] = n;
+            const uint32_t low = k == 0 ? low0 : ((1u << (k * GW)) - 1u) | (low0 << (k * GW));   // ranked before column k of mine
+            const uint64_t ch = bal((int)__popc(gf & low) == rr) & bo[k];
+            *lds_at<int>(lanes(ch) ? selw : scratch) = (int)g.ent[k];
         }
         if (lanes(lead_m)) lds_at<int>(selw)[1] = __popc(qf);
         wave_lds_fence();
@@ -2529,9 +2528,11 @@ struct HalfScan {
         wave_lds_fence();
     }
 };
+// columns per lane the half-wave scan needs for a pool whose widest row has max_deg entries (0: use the paired scan)
+__host__ __device__ constexpr int half_scan_gw(int P) { return 32 / (P + 1) > kD ? kD : 32 / (P + 1); }
 
 // ---- the move wave -----------------------------------------------------------------------------
-template <int NR, bool REC, int PT, bool POL, bool HS>   // HS: half-wave neighbour scan (no row of the pool wider than 2 GW)
+template <int NR, bool REC, int PT, bool POL, int HS>   // HS > 0: half-wave neighbour scan with HS columns per lane (no row of the pool wider than HS * GW)
 __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& L, const EnvLds& E, const EnvLds& E1, int lane, int e,
                                            int g, int slot, int T, sy_rollout_buffers out) {
     const int P = PT > 0 ? PT : p.P, A = P + 1;
@@ -2587,9 +2588,9 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
     }
     wave_lds_fence();
     // up to 5 agents, random policy (police count fixed at compile time): one episode per half wave in the scan
-    constexpr bool HALF = HS && !POL && PT >= 1 && PT <= 4;
-    constexpr int GWH = HALF ? (32 / (PT + 1) > kD ? kD : 32 / (PT + 1)) : kD;
-    HalfScan<GWH> hs;
+    constexpr bool HALF = HS > 0 && !POL && PT >= 1 && PT <= 6;
+    constexpr int GWH = HALF ? half_scan_gw(PT) : kD;
+    HalfScan<GWH, (HALF ? HS : 1)> hs;
     if (HALF) hs.init(L, E, E1, lane, A, NS);
     PairScanLane psl = make_pair_scan_lane(E, E1, sm, lane, A, NS);
     PairScanLane psl2 = psl;
@@ -2734,7 +2735,7 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         }
         sc_v = nxt_v;
         const uint32_t x_next = xw[0];
-        typename HalfScan<GWH>::In hg;
+        typename HalfScan<GWH, (HALF ? HS : 1)>::In hg;
         ScanPairIn sg, sg2;
         if (HALF) {
             hg = hs.gather(pos_v, mon_v, x_next);
@@ -3230,7 +3231,7 @@ __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap
 
 // Block = wpb episodes (even): wpb / 2 move waves, then wpb / 2 helper waves — one wave per episode, 16 episodes
 // per 1024-thread block (one block per CU at B = 4096), 4 waves per SIMD.
-template <int NR, bool REC, int PT, bool POL = false, bool HS = false>   // POL: actions from the MAPPO actors (sy_env_set_policy); HS: half-wave scan
+template <int NR, bool REC, int PT, bool POL = false, int HS = 0>   // POL: actions from the MAPPO actors (sy_env_set_policy); HS: half-wave scan, columns per lane
 __global__ __launch_bounds__(1024, 4) void rollout3_kernel(const EngineParams p, const int T, const sy_rollout_buffers out_arg) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -3896,11 +3897,48 @@ __global__ __launch_bounds__(256) void returns_kernel(const ReturnsArgs a) {
 // ---------------------------------------------------------------------------------------------
 // host-side launchers (called from the C ABI, sy_capi.hip)
 // ---------------------------------------------------------------------------------------------
+// The half-wave neighbour scan (random policy): `cols` columns per scan lane cover the pool's widest row.  Instances:
+// 2 columns for up to 5 agents (any board size up to 256 nodes); boards of 129..256 nodes also 2 / 3 columns at 6
+// agents and 3 / 4 at 7 agents.  Returns false when no instance fits (the caller takes the paired scan).
+template <int NR, int PT, bool REC, int COLS>
+static void launch_half_instance(const EngineParams& p, int T, const sy_rollout_buffers& out, int blocks, int threads3, size_t lds,
+                                 hipStream_t stream) {
+    hipLaunchKernelGGL((rollout3_kernel<NR, REC, PT, false, COLS>), dim3(blocks), dim3(threads3), lds, stream, p, T, out);
+}
+template <int NR, int PT>
+static bool launch_half_scan(const EngineParams& p, int T, const sy_rollout_buffers& out, int cols, int blocks, int threads3, size_t lds,
+                             hipStream_t stream) {
+    if (cols <= 0) return false;
+    if constexpr (NR <= 4 && PT >= 1 && PT <= 4) {
+        if (cols > 2) return false;
+        if (out.record) launch_half_instance<NR, PT, true, 2>(p, T, out, blocks, threads3, lds, stream);
+        else launch_half_instance<NR, PT, false, 2>(p, T, out, blocks, threads3, lds, stream);
+        return true;
+    } else if constexpr (NR == 4 && (PT == 5 || PT == 6)) {
+        constexpr int C0 = PT == 5 ? 2 : 3, C1 = C0 + 1;
+        if (cols > C1) return false;
+        if (cols <= C0) {
+            if (out.record) launch_half_instance<NR, PT, true, C0>(p, T, out, blocks, threads3, lds, stream);
+            else launch_half_instance<NR, PT, false, C0>(p, T, out, blocks, threads3, lds, stream);
+        } else {
+            if (out.record) launch_half_instance<NR, PT, true, C1>(p, T, out, blocks, threads3, lds, stream);
+            else launch_half_instance<NR, PT, false, C1>(p, T, out, blocks, threads3, lds, stream);
+        }
+        return true;
+    } else {
+        return false;
+    }
+}
+
 template <int NR>
 static hipError_t launch_engine_nr(const EngineParams& p, const int32_t* actions, int T, const sy_rollout_buffers& out,
                                    bool ext, int blocks, int wpb, size_t lds, hipStream_t stream) {
 #ifdef SY_ISA_ONLY   // tools/isa_only.sh: only the headline instance, for a quick look at its ISA (not a usable library)
-    if (NR == 4) hipLaunchKernelGGL((rollout3_kernel<4, true, 4, false, true>), dim3(blocks), dim3(64 * wpb), lds, stream, p, T, out);
+#ifndef SY_ISA_PT
+#define SY_ISA_PT 4
+#define SY_ISA_HS 2
+#endif
+    if (NR == 4) hipLaunchKernelGGL((rollout3_kernel<4, true, SY_ISA_PT, false, SY_ISA_HS>), dim3(blocks), dim3(64 * wpb), lds, stream, p, T, out);
     return hipGetLastError();
 #else
     if (ext) {
@@ -3924,6 +3962,12 @@ static hipError_t launch_engine_nr(const EngineParams& p, const int32_t* actions
 #endif
         const int threads = paired ? 64 * (wpb / 2 + (p.st.belief ? wpb / 2 : 0))
                                    : 64 * (wpb + (p.st.belief ? (wpb + 1) / 2 : 0));   // move waves + belief waves
+        // half-wave scan (random policy, up to 7 agents): columns per lane that cover the pool's widest row; 0 = paired scan.
+        // Instances: 2 columns for up to 5 agents (any board size), and for boards of 129..256 nodes 2 / 3 columns at
+        // 6 agents, 3 / 4 at 7 agents.
+        const int hs_gw = half_scan_gw(p.P);
+        const int hs_need = (p.max_deg + hs_gw - 1) / hs_gw;
+        const int hs_cols = (p.pw2 == nullptr && p.A <= 7 && hs_need * hs_gw <= 32) ? hs_need : 0;
 #define SY_LAUNCH_ROLLOUT(PT_)                                                                                            \
     do {                                                                                                                  \
         if (paired && pipelined && pol_pipeline && p.pw2 != nullptr && p.A <= per_pass) {                                 \
@@ -3932,12 +3976,8 @@ static hipError_t launch_engine_nr(const EngineParams& p, const int32_t* actions
         } else if (paired && p.pw2 != nullptr) {                                                                          \
             hipLaunchKernelGGL((rollout2_kernel<NR, true, (PT_ == 4 ? 4 : 0), true>), dim3(blocks), dim3(threads),        \
                                lds + (size_t)wpb * SY_POLICY_SLICE, stream, p, T, out);                                    \
-        } else if (paired && pipelined && PT_ >= 1 && PT_ <= 4 && p.max_deg <= 2 * (32 / (PT_ + 1))) {                     \
-            /* up to 5 agents and no row wider than two columns per scan lane: the half-wave scan */                      \
-            if (out.record)                                                                                               \
-                hipLaunchKernelGGL((rollout3_kernel<(NR <= 4 ? NR : 1), true, (PT_ >= 1 && PT_ <= 4 ? PT_ : 1), false, true>), dim3(blocks), dim3(threads3), lds, stream, p, T, out);\
-            else                                                                                                          \
-                hipLaunchKernelGGL((rollout3_kernel<(NR <= 4 ? NR : 1), false, (PT_ >= 1 && PT_ <= 4 ? PT_ : 1), false, true>), dim3(blocks), dim3(threads3), lds, stream, p, T, out);\
+        } else if (paired && pipelined && launch_half_scan<NR, PT_>(p, T, out, hs_cols, blocks, threads3, lds, stream)) {  \
+            /* launched with the half-wave neighbour scan */                                                              \
         } else if (paired && pipelined) {                                                                                 \
             if (out.record)                                                                                               \
                 hipLaunchKernelGGL((rollout3_kernel<(NR <= 4 ? NR : 1), true, PT_>), dim3(blocks), dim3(threads3), lds, stream, p, T, out);\

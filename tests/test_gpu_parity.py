@@ -222,6 +222,29 @@ def test_fused_rollout_scan_widths_and_passes(sy, ol, police, hub_degree):
     env.close()
 
 
+@pytest.mark.parametrize("police,hub_degree", [(5, 10), (5, 11), (5, 15), (5, 16), (6, 8), (6, 12), (6, 13), (6, 16), (4, 12), (4, 16)])
+def test_half_wave_scan_columns_on_mid_size_boards(sy, ol, police, hub_degree):
+    """Boards of 129..256 nodes: 6 and 7 agents take the half-wave scan with 2..4 columns per lane (5 / 4 columns per
+    agent and pass); every column count and the fallback to the paired scan (6 agents at rows of 16) against the oracle."""
+    rng = np.random.default_rng(77 * police + hub_degree)
+    N, B, T = 136, 48, 50
+    boards = [_hub_board(sy, N, hub_degree, rng) for _ in range(2)]
+    weights = rng.uniform(0.05, 0.95, 11)
+    env = sy.BatchedScotlandYardEnv(B, boards, police, 9, weights, seed=31, reveal_interval=4)
+    assert env.max_degree == hub_degree
+    graphs = [ol.OracleGraph(N, b.edge_links, b.edges.astype(np.int32)) for b in boards]
+    orc = ol.OracleBatch(graphs, env.env_graph_host, B, police, 9, node_stride=env.NS, weights=weights,
+                         tables=sy.reward_tables(), reveal_interval=4)
+    orc.reset(seed=31)
+    rec = env.rollout(T)
+    ref = orc.rollout(T)
+    for k in ("pos", "t", "action", "terminated", "truncated", "winner", "mask", "reward"):
+        np.testing.assert_array_equal(_np(rec[k]), ref[k], err_msg=k)
+    np.testing.assert_allclose(_np(rec["belief"]), ref["belief"], rtol=0, atol=BELIEF_TOL)
+    _compare_state(env, orc, "after half-wave scan rollout")
+    env.close()
+
+
 def test_rollout_equals_stepping_its_own_actions(sy):
     """Fused sampling path == caller-action path: replaying the recorded actions through step()."""
     boards = sy.sample_board_pool(2, 60, 100, seed=21)

@@ -2450,16 +2450,22 @@ struct HalfScan {
     static constexpr uint32_t kField = (1u << GW) - 1u;
     uint32_t row, selw, selr, scratch, low0, bsrc, bsrcq, ell_col;
     uint32_t prev[NC];
-    int gsh, col;
+    int gsh, col, ag;
     uint64_t on_m, lead_m;
     struct In { uint32_t ent[NC]; uint32_t xa; int ma, mq; };
+    struct Pol {                 // learned policy (sy_env_set_policy): my group's actor and its LDS scratch, my episode
+        uint32_t hs, sl, slr;
+        const float* w2a;
+        const float* b2a;
+        float thr;               // log(1e-8) + log(N) + bound[agent]   (+inf without a bound: never the exact path)
+    };
 
     __device__ __forceinline__ void init(const LdsMap& L, const EnvLds& E, const EnvLds& E1, int lane, int A, int NS) {
         const bool up = lane >= 32;
         const int li = lane & 31, grp = li / GW;
         col = li - grp * GW;
         const bool on = grp < A;
-        const int ag = on ? grp : 0;
+        ag = on ? grp : 0;
         const uint32_t rec_h = lds_off(up ? E1.rec_s : E.rec_s);
         row = lds_off(up ? E1.mrow : E.mrow) + (uint32_t)(ag * NS);
         selw = rec_h + (uint32_t)(kSelWord + 2 * ag) * 4u;
@@ -2527,6 +2533,152 @@ struct HalfScan {
         quirk_cnt = (int)(r >> 32);
         wave_lds_fence();
     }
+
+    // ---- the learned policy choosing the action (scan_eval_pair_policy3 in the half-wave layout) ----
+    __device__ __forceinline__ Pol make_pol(const EngineParams& p, int lane, int A, uint32_t pol0, uint32_t pol1) const {
+        Pol q;
+        const int H = p.pH;
+        const uint32_t pb = lane >= 32 ? pol1 : pol0;
+        const uint32_t slots = (uint32_t)(A * H) * 4u;
+        q.hs = pb + (uint32_t)(ag * H) * 4u;
+        q.sl = pb + slots + 16u * (uint32_t)ag;
+        q.slr = pb + slots + 16u * (uint32_t)(lane & 7);
+        q.w2a = p.pw2 + (size_t)ag * p.N * H;
+        q.b2a = p.pb2 + (size_t)ag * p.N;
+        q.thr = p.pbound ? (-18.420680744f + __logf((float)p.N) + p.pbound[ag]) : -3.0e38f;
+        return q;
+    }
+    // one logit: the neighbour's row of w2 (L2) against the agent's hidden vector (LDS), the reference's summation order
+    template <int BATCH>
+    static __device__ __forceinline__ float logit_of(const Pol& pl, uint32_t nb, int H) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        float l = pl.b2a[nb];
+        const f4* r0 = reinterpret_cast<const f4*>(pl.w2a + (size_t)nb * H);
+        const int nq = H >> 2;
+        int c = 0;
+        for (; c + BATCH <= nq; c += BATCH) {
+            f4 a[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) a[u] = r0[c + u];
+#pragma unroll
+            for (int u = 0; u < BATCH; ++u) {
+                const f4 h0 = *lds_at<f4>(pl.hs + 16u * (uint32_t)(c + u));
+                l = fmaf(a[u].x, h0.x, l); l = fmaf(a[u].y, h0.y, l); l = fmaf(a[u].z, h0.z, l); l = fmaf(a[u].w, h0.w, l);
+            }
+        }
+        for (; c < nq; ++c) {
+            const f4 a0 = r0[c];
+            const f4 h0 = *lds_at<f4>(pl.hs + 16u * (uint32_t)c);
+            l = fmaf(a0.x, h0.x, l); l = fmaf(a0.y, h0.y, l); l = fmaf(a0.z, h0.z, l); l = fmaf(a0.w, h0.w, l);
+        }
+        return l;
+    }
+    template <int NR>
+    __device__ __forceinline__ void eval_policy(const In& g, const Pol& pl, int H, int N, int lane, const float* w2_all,
+                                                const float* b2_all, int& act_v, int& cost_v, int& quirk_cnt, float& logp_v) {
+        if (lanes(kAgentSlots)) {
+            *lds_at<uint64_t>(selr) = 0x0000ffffull;                                     // "no move": action -1, cost 0
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            *lds_at<v4i>(pl.slr) = (v4i){(int)0x80000000, (int)0x80000000, 0, 0};         // max key, max logit, sum exp, log-prob
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k) *lds_at<uint8_t>(prev[k]) = 0;
+        uint64_t bo[NC];
+        uint32_t nb[NC];
+        uint32_t gf = 0, qf = 0;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            const int w = (int)(g.ent[k] >> 16);
+            bo[k] = bal(w <= g.ma) & on_m;
+            const uint64_t bq = bal(w <= g.mq) & on_m;
+            gf |= ((uint32_t)(bo[k] >> gsh) & kField) << (k * GW);
+            qf |= ((uint32_t)(bq >> gsh) & kField) << (k * GW);
+            const bool own = lanes(bo[k]);
+            nb[k] = own ? (g.ent[k] & 0xffffu) : 0u;
+            const uint32_t n = own ? row + nb[k] : scratch;
+            *lds_at<uint8_t>(n) = 1;
+            prev[k] = n;
+        }
+        // logits of the affordable entries: the first column of every lane, further columns only on the steps where
+        // some agent of the pair stands on a row that wide (wave-uniform)
+#ifndef SY_POL_BATCH_HALF
+#define SY_POL_BATCH_HALF 4
+#endif
+        float l[NC];
+        l[0] = logit_of<SY_POL_BATCH_HALF>(pl, nb[0], H);
+#pragma unroll
+        for (int k = 1; k < NC; ++k) {
+            l[k] = 0.0f;
+            if (bo[k] != 0ull) l[k] = logit_of<SY_POL_BATCH_HALF>(pl, nb[k], H);
+        }
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+            if (lanes(bo[k])) atomicMax(lds_at_generic<int>(pl.sl + 4u), f32_ordered(l[k]));
+        wave_lds_fence();
+        float Lm = ordered_f32(*lds_at<int>(pl.sl + 4u));
+#pragma unroll
+        for (int k = 0; k < NC; ++k)
+            if (lanes(bo[k])) atomicAdd(lds_at_generic<float>(pl.sl + 8u), __expf(l[k] - Lm));
+        wave_lds_fence();
+        float S = *lds_at<float>(pl.sl + 8u);
+        // ---- the reference's underflow rule (mappo_agent.py:123-134), exact only where the cheap bound cannot rule it out
+        {
+            const bool lead = lanes(lead_m);
+            const uint64_t sus = bal(lead && gf != 0u && !(Lm + __logf(S) > pl.thr));
+            uint64_t fb = 0ull;                       // groups (leader-lane bits) that fall back to uniform over the mask
+#ifndef SY_POL_NO_FALLBACK
+            if (sus != 0ull) {                        // rare: evaluate the suspicious actors exactly, one (episode, agent) at a time
+                uint64_t todo = sus;
+                while (todo != 0ull) {
+                    const int ll = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1ull;
+                    const int agu = rdlane(ag, ll);
+                    const uint32_t hsu = (uint32_t)rdlane((int)pl.hs, ll);
+                    const float lse = __int_as_float(rdlane(__float_as_int(Lm + __logf(S)), ll));
+                    const float mass = exact_legal_mass<NR>(w2_all + (size_t)agu * N * H, b2_all + (size_t)agu * N, hsu, H, N, lane, lse);
+                    if (mass <= 1e-8f) fb |= 1ull << ll;
+                }
+            }
+#endif
+            if (fb != 0ull) {                         // my group's leader bit -> my fallback flag
+                const bool f = ((fb >> (lane - col)) & 1ull) != 0ull;
+#pragma unroll
+                for (int k = 0; k < NC; ++k) l[k] = f ? 0.0f : l[k];
+                Lm = f ? 0.0f : Lm;
+                S = f ? (float)__popc(gf) : S;
+            }
+        }
+        // Gumbel-max draw: a cheap per-entry hash (ELL column) of the agent's Philox word of this step
+        auto gumbel = [](uint32_t x, uint32_t column) {
+            uint32_t h = x ^ (column * 0x9E3779B9u) ^ 0x85EBCA6Bu;
+            h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+            const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            return -__logf(-__logf(u));
+        };
+        float key[NC];
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            key[k] = l[k] + gumbel(g.xa, (uint32_t)(k * GW + col));
+            if (lanes(bo[k])) atomicMax(lds_at_generic<int>(pl.sl), f32_ordered(key[k]));
+        }
+        wave_lds_fence();
+        const int kmax = *lds_at<int>(pl.sl);
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            if (lanes(bo[k]) && f32_ordered(key[k]) == kmax) {
+                *lds_at<int>(selw) = (int)g.ent[k];
+                *lds_at<float>(pl.sl + 12u) = (l[k] - Lm) - __logf(S);
+            }
+        }
+        if (lanes(lead_m)) lds_at<int>(selw)[1] = __popc(qf);
+        wave_lds_fence();
+        const uint64_t r = *lds_at<uint64_t>(selr);
+        act_v = (int)(int16_t)(uint32_t)r;              // 0xffff -> -1
+        cost_v = (int)(((uint32_t)r) >> 16);
+        quirk_cnt = (int)(r >> 32);
+        logp_v = *lds_at<float>(pl.slr + 12u);
+        wave_lds_fence();
+    }
 };
 // columns per lane the half-wave scan needs for a pool whose widest row has max_deg entries (0: use the paired scan)
 __host__ __device__ constexpr int half_scan_gw(int P) { return 32 / (P + 1) > kD ? kD : 32 / (P + 1); }
@@ -2588,7 +2740,7 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
     }
     wave_lds_fence();
     // up to 5 agents, random policy (police count fixed at compile time): one episode per half wave in the scan
-    constexpr bool HALF = HS > 0 && !POL && PT >= 1 && PT <= 6;
+    constexpr bool HALF = HS > 0 && PT >= 1 && PT <= 6;
     constexpr int GWH = HALF ? half_scan_gw(PT) : kD;
     HalfScan<GWH, (HALF ? HS : 1)> hs;
     if (HALF) hs.init(L, E, E1, lane, A, NS);
@@ -2596,9 +2748,17 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
     PairScanLane psl2 = psl;
     if (!one_pass) psl2 = make_pair_scan_lane(E, E1, sm, lane, A, NS, sm.per_pass);
     int act_v = -1, cost_v = 0, qcnt = 0;
+    typename HalfScan<GWH, (HALF ? HS : 1)>::Pol hpl;
+    if (HALF && POL) hpl = hs.make_pol(p, lane, A, pol0, pol1);
     if (HALF) {
         const auto g0 = hs.gather(pos_v, mon_v, xw[0]);
-        hs.eval(g0, act_v, cost_v, qcnt);
+        if (POL) {
+            policy_hidden_pair3(p, P, A, pos_v, lane, pol0, pol1);
+            wave_lds_fence();
+            hs.template eval_policy<NR>(g0, hpl, p.pH, N, lane, p.pw2, p.pb2, act_v, cost_v, qcnt, logp_v);
+        } else {
+            hs.eval(g0, act_v, cost_v, qcnt);
+        }
     } else {
         const ScanPairIn g0 = scan_gather_pair(L.ell_s, A, sm, 0, pos_v, mon_v, xw[0]);
         if (POL) {           // (the launcher only picks this instance for single-pass boards)
@@ -2796,7 +2956,8 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         S3(3)
         // ---- evaluate half of the scan: masks of the new state, position-reward counts, next action
         if (HALF) {
-            hs.eval(hg, act_v, cost_v, qcnt);
+            if (POL) hs.template eval_policy<NR>(hg, hpl, p.pH, N, ln, p.pw2, p.pb2, act_v, cost_v, qcnt, logp_v);
+            else hs.eval(hg, act_v, cost_v, qcnt);
         } else if (POL) {
             scan_eval_pair_policy3<NR>(psl, pll, sm, p.scan_w, p.pH, N, ln, p.pw2, p.pb2, sg, act_v, cost_v, qcnt, logp_v);
         } else if (one_pass) {
@@ -3967,10 +4128,14 @@ static hipError_t launch_engine_nr(const EngineParams& p, const int32_t* actions
         // 6 agents, 3 / 4 at 7 agents.
         const int hs_gw = half_scan_gw(p.P);
         const int hs_need = (p.max_deg + hs_gw - 1) / hs_gw;
-        const int hs_cols = (p.pw2 == nullptr && p.A <= 7 && hs_need * hs_gw <= 32) ? hs_need : 0;
+        const int hs_cols = (p.A <= 7 && hs_need * hs_gw <= 32) ? hs_need : 0;
 #define SY_LAUNCH_ROLLOUT(PT_)                                                                                            \
     do {                                                                                                                  \
         if (paired && pipelined && pol_pipeline && p.pw2 != nullptr && p.A <= per_pass) {                                 \
+            if (PT_ == 4 && hs_cols > 0 && hs_cols <= 2)    /* 4 police: the half-wave scan, one logit stream per lane */ \
+                hipLaunchKernelGGL((rollout3_kernel<(NR <= 4 ? NR : 1), true, 4, true, 2>), dim3(blocks),                  \
+                                   dim3(threads3), lds + (size_t)wpb * p.pslice, stream, p, T, out);                       \
+            else                                                                                                          \
             hipLaunchKernelGGL((rollout3_kernel<(NR <= 4 ? NR : 1), true, (PT_ == 4 ? 4 : 0), true>), dim3(blocks),        \
                                dim3(threads3), lds + (size_t)wpb * p.pslice, stream, p, T, out);                           \
         } else if (paired && p.pw2 != nullptr) {                                                                          \

@@ -2866,6 +2866,9 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         S3(0)
         // ---- a finished episode restarts right here: the one scan below already serves the new episode
         const int pos_m = pos_v;           // post-move nodes: the visit counters and the shaped rewards use these
+        // every agent's post-move node goes to LDS now (the result-slot words of the staging row, free until the scan is
+        // evaluated): by the time the shortest-path gathers read them back, the write is long done
+        if (!POL && lanes(kAgentSlots)) lds_at<int>(xch_off)[a] = pos_m;
         const int t_rew = t_v;             // pre-increment timestep of this step (reward_calculator.py:145,219)
         if (NEED != 0ull) {
             const int st = sample_starts_pair(NEED, ln, a, A, N, gid, sc_v + 1u, p.seed_lo, p.seed_hi);
@@ -2906,24 +2909,35 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         }
         if (POL) policy_hidden_pair3(p, P, A, pos_v, ln, pol0, pol1);      // hidden vectors of the next observation
         S3(2)
-        // ---- node_visit_counts (yard.py:244-245), then every agent's post-move node to every lane of its half through
-        // LDS (the result-slot words of the staging row, free until the scan is evaluated), then the shortest-path gathers
+        // ---- node_visit_counts (yard.py:244-245); then the LDS reads of this phase issued back to back — every agent's
+        // post-move node (for the shortest-path gathers) and the mask rows of the observation before the step (LDS
+        // operations of a wave are in order: these reads see the rows before the scan below rewrites them) — one
+        // round trip instead of three; then the shortest-path loads, then the mask stores (stores queued ahead of
+        // loads would delay them)
         int vc = 0;
         int dm = 0;
         int dj[SY_MAX_AGENTS - 1];
 #pragma unroll
         for (int j = 1; j < SY_MAX_AGENTS; ++j) dj[j - 1] = 0;
+        typedef int v4i __attribute__((ext_vector_type(4)));
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        v4i qa = {0, 0, 0, 0}, qb = {0, 0, 0, 0};
         if (!POL) {
             SY_HOT(m_visits);
-            if (is_pol) vc = (int)atomicAdd(vis32 + pos_m, 1u) + 1;
+            if (is_pol) vc = (int)atomicAdd(vis32 + pos_m, 1u);     // (the count before this visit: + 1 where it is used, so nothing waits here)
             if (NEED != 0ull) {                // a new episode starts from zero (yard.py:85)
                 if (lanes(NEED))
                     for (int i = a; i < (NS >> 2); i += 32) reinterpret_cast<uint4*>(vis32)[i] = make_uint4(0, 0, 0, 0);
             }
-            if (lanes(kAgentSlots)) lds_at<int>(xch_off)[a] = pos_m;
-            wave_lds_fence();
-            typedef int v4i __attribute__((ext_vector_type(4)));
-            const v4i qa = *lds_at<v4i>(xch_off), qb = *lds_at<v4i>(xch_off + 16u);
+            qa = *lds_at<v4i>(xch_off);
+            qb = *lds_at<v4i>(xch_off + 16u);
+        }
+        // 16-byte pieces c, c + 32, c + 64 of my episode's rows (pieces past the end are clamped to the last one: a few
+        // lanes then store the same bytes to the same address, which is cheaper than masking them off)
+        const bool rec_mask = REC && out.mask;
+        v4u v0, v1, v2;
+        if (REC) { v0 = *lds_at<v4u>(mc_lds0); v1 = *lds_at<v4u>(mc_lds1); v2 = *lds_at<v4u>(mc_lds2); }
+        if (!POL) {
             const int q[SY_MAX_AGENTS] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
             const uint32_t rowb = (uint32_t)(pos_m * N) * 2u;
             if (is_pol) {
@@ -2933,13 +2947,7 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
                     if (j <= P) dj[j - 1] = (int)*at_bytes(ap, rowb + (uint32_t)q[j] * 2u);
             }
         }
-        // ---- the mask rows of the observation before the step go to the record (LDS operations of a wave are in
-        // order: these reads see the rows before the scan below rewrites them)
-        if (REC && out.mask) {
-            // 16-byte pieces c, c + 32, c + 64 of my episode's rows (pieces past the end are clamped to the last one:
-            // a few lanes then store the same bytes to the same address, which is cheaper than masking them off)
-            typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-            const v4u v0 = *lds_at<v4u>(mc_lds0), v1 = *lds_at<v4u>(mc_lds1), v2 = *lds_at<v4u>(mc_lds2);
+        if (rec_mask) {
             if (store_ok) {
                 SY_HOT(m_maskcopy);
                 *reinterpret_cast<v4u*>(out.mask + mc_off0) = v0;
@@ -2970,7 +2978,8 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         // ---- rewards of the step (reward_calculator.py:63-90 constants, :94-266 shaped)
         if (!POL) {
             SY_HOT(m_rewards);
-            const double shaped = shaped_reward3(tb, a, P, POLM, t_rew, qcnt, vc, dm, dj, kc);
+            asm volatile("" : "+v"(vc));       // (keeps the "+ 1" — and with it the wait for the LDS add — down here)
+            const double shaped = shaped_reward3(tb, a, P, POLM, t_rew, qcnt, is_pol ? vc + 1 : 0, dm, dj, kc);
             rew = lanes(ENDED) ? (lanes(CAP) ? (a == 0 ? -1.0 : 1.0) : (a == 0 ? 1.0 : 0.0)) : shaped;
         }
         S3(6)

@@ -51,6 +51,13 @@ static constexpr int kRing = SY_RING;          // move wave -> belief wave ring 
 #endif
 static constexpr int kSpinMax = SY_SPIN_MAX;   // every spin is bounded: a lost partner cannot hang the GPU
 
+// The trajectory record is written once and read by nobody inside the launch: streaming (non-temporal) stores.
+#ifdef SY_NO_STREAM_STORES
+#define SY_STREAM_STORE(ptr, val) (*(ptr) = (val))
+#else
+#define SY_STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#endif
+
 #ifdef SY_ISA_ONLY   // way-points for tools/isa_hot.py (comments in the assembly listing of the ISA-only build)
 #define SY_HOT(tag) asm volatile("; SYHOT " #tag)
 #else
@@ -2950,9 +2957,9 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         if (rec_mask) {
             if (store_ok) {
                 SY_HOT(m_maskcopy);
-                *reinterpret_cast<v4u*>(out.mask + mc_off0) = v0;
-                *reinterpret_cast<v4u*>(out.mask + mc_off1) = v1;
-                *reinterpret_cast<v4u*>(out.mask + mc_off2) = v2;
+                SY_STREAM_STORE(reinterpret_cast<v4u*>(out.mask + mc_off0), v0);
+                SY_STREAM_STORE(reinterpret_cast<v4u*>(out.mask + mc_off1), v1);
+                SY_STREAM_STORE(reinterpret_cast<v4u*>(out.mask + mc_off2), v2);
                 if (n16 > 96) {
                     uint4* md = reinterpret_cast<uint4*>(out.mask + off_mask);
                     const uint4* mr = reinterpret_cast<const uint4*>(mrow_h) + a;
@@ -3088,8 +3095,8 @@ struct BeliefLanes {
             vNf v0, v1;
 #pragma unroll
             for (int k = 0; k < NR; ++k) { v0[k] = b[k].x; v1[k] = b[k].y; }
-            *reinterpret_cast<vNf*>(at_bytes(row_base, off_bel)) = v0;
-            if (live1) *reinterpret_cast<vNf*>(at_bytes(row_base, off_bel + (uint32_t)NS * 4u)) = v1;
+            SY_STREAM_STORE(reinterpret_cast<vNf*>(at_bytes(row_base, off_bel)), v0);
+            if (live1) SY_STREAM_STORE(reinterpret_cast<vNf*>(at_bytes(row_base, off_bel + (uint32_t)NS * 4u)), v1);
         }
     }
     // one transition: bf = 0 filter step, 1 new episode (prior), 2 reveal (delta on MrX's node)

@@ -134,7 +134,9 @@ int sy_env_destroy(sy_env *env);
 int sy_env_launch_info(const sy_env *env, int32_t *waves_per_block, int32_t *blocks, int32_t *lds_bytes);
 
 /* board + shortest-path tables (replaces board.edge_links/edges yard.py:91-93 and Pathfinder.set_board
- * pathfinding.py:25-32); all device pointers */
+ * pathfinding.py:25-32); all device pointers.  max_degree is the widest ELL row of the pool: it sizes the neighbour
+ * scan of the fused rollout (the half-wave scan needs rows of at most 12 neighbours at 4 police, 15 / 16 at 5 / 6 on
+ * boards of 129..256 nodes; wider pools, and 0 = unknown, take the general paired scan — same results, slower) */
 int sy_env_set_graph_pool(sy_env *env, const uint32_t *ell, const uint16_t *apsp, const float *inv_deg,
                           const int32_t *env_graph, int32_t max_degree /* widest ELL row of the pool; 0 = unknown */);
 /* the 11 reward weights (host array, order = REWARD_WEIGHT_NAMES reward_net.py:5-17) and the device

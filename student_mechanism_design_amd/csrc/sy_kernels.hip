@@ -3049,7 +3049,7 @@ struct BeliefLanes {
     float ideg[NR];
     uint32_t ga[NR][8];                                    // LDS addresses of the first eight neighbour entries
     int slab_w[NR];
-    uint64_t in_m[NR], iso_m[NR];                          // lanes whose node k exists / has no neighbour
+    uint64_t in_m[NR];                                     // lanes whose node k exists
     uint32_t c_off, c_mine, off_bel;
     int j0;
     bool mine;
@@ -3077,6 +3077,16 @@ struct BeliefLanes {
             ga[k][4] = c_off + (o.z & 0xffffu); ga[k][5] = c_off + (o.z >> 16);
             ga[k][6] = c_off + (o.w & 0xffffu); ga[k][7] = c_off + (o.w >> 16);
             const int deg = ideg[k] > 0.0f ? (int)(1.0f / ideg[k] + 0.5f) : 0;
+            // Two special cases folded into the gather addresses so that the step needs no per-node selects: lanes past
+            // the board gather the zero entry only (their belief stays 0), and a node without neighbours (the mass on
+            // it stays: belief_module.py keeps the particle) gathers ITSELF once with weight 1 — b * 1 + zeros == b.
+            const uint32_t zero_e = c_off + (uint32_t)N * 8u;
+            const bool inr = mine && j < N;
+            if (!inr || deg == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) ga[k][q] = zero_e;
+                if (inr) { ga[k][0] = c_off + (uint32_t)j * 8u; ideg[k] = 1.0f; }
+            }
             int need = (deg + 3) >> 2;
 #pragma unroll
             for (int o2 = 32; o2 >= 1; o2 >>= 1) {
@@ -3085,7 +3095,6 @@ struct BeliefLanes {
             }
             slab_w[k] = rdlane(need, 0);
             in_m[k] = bal(j < N);
-            iso_m[k] = bal(ideg[k] == 0.0f);
         }
         if (lane == 0) *lds_at<v2f>(c_off + (uint32_t)N * 8u) = (v2f){0.0f, 0.0f};   // padding entries point here
     }
@@ -3131,7 +3140,7 @@ struct BeliefLanes {
                 for (int q = 0; q < GR; ++q) {
                     const int r = r0 + q;
                     const int j = j0 + r;
-                    v2f acc = lanes(iso_m[r]) ? b[r] : (v2f){0.0f, 0.0f};
+                    v2f acc = {0.0f, 0.0f};
                     acc += ((gq[q][0] + gq[q][1]) + (gq[q][2] + gq[q][3])) + ((gq[q][4] + gq[q][5]) + (gq[q][6] + gq[q][7]));
                     if (slab_w[r] > 2) {            // wave-uniform: some node of this group has more than 8 neighbours
                         const int jr = j < N ? j : N - 1;
@@ -3141,6 +3150,7 @@ struct BeliefLanes {
                         const v2f x0 = ld(o2.x & 0xffffu), x1 = ld(o2.x >> 16), x2 = ld(o2.y & 0xffffu), x3 = ld(o2.y >> 16);
                         const v2f x4 = ld(o2.z & 0xffffu), x5 = ld(o2.z >> 16), x6 = ld(o2.w & 0xffffu), x7 = ld(o2.w >> 16);
                         acc += ((x0 + x1) + (x2 + x3)) + ((x4 + x5) + (x6 + x7));
+                        acc = lanes(in_m[r]) ? acc : (v2f){0.0f, 0.0f};       // (lanes past the board read a clamped row here)
                     }
                     if (pol_ev) {
 #pragma unroll
@@ -3149,7 +3159,6 @@ struct BeliefLanes {
                             if (k < P && j == pol1[k]) acc.y = 0.0f;
                         }
                     }
-                    acc = lanes(in_m[r]) ? acc : (v2f){0.0f, 0.0f};
                     b[r] = acc;
                     tot += acc;
                 }

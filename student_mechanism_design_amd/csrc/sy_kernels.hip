@@ -3345,8 +3345,9 @@ __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap
         // ---- belief: new episode -> prior, reveal -> delta on MrX's node, else one filter step
         if (has_belief) {
             const int node0 = rdlane(pos1_v, 0), node1 = rdlane(pos1_v, 32);
-            const int bf0 = (f_lo & kFlagRestart) ? 1 : ((f_lo & kFlagReveal) ? 2 : 0);
-            const int bf1 = (f_hi & kFlagRestart) ? 1 : ((f_hi & kFlagReveal) ? 2 : 0);
+            // new episode -> 1, reveal -> 2, else 0: the two marks are adjacent bits and never set together
+            static_assert(kFlagRestart == 16 && kFlagReveal == 32, "bf = (flags >> 4) & 3");
+            const int bf0 = (f_lo >> 4) & 3, bf1 = (f_hi >> 4) & 3;
             int pol0[SY_MAX_AGENTS - 1], pol1[SY_MAX_AGENTS - 1];
 #pragma unroll
             for (int k = 0; k < SY_MAX_AGENTS - 1; ++k) pol0[k] = pol1[k] = -1;

@@ -245,6 +245,28 @@ def test_half_wave_scan_columns_on_mid_size_boards(sy, ol, police, hub_degree):
     env.close()
 
 
+@pytest.mark.parametrize("N,P,B", [(200, 4, 33), (200, 4, 1), (200, 6, 17), (199, 5, 31), (136, 2, 5), (64, 4, 19), (200, 4, 4097)])
+def test_odd_batches_match_oracle(sy, ol, N, P, B):
+    """Batches that leave a pair of episodes half empty (the move / helper waves carry two episodes): the last wave of
+    the last block simulates a duplicate whose stores are suppressed — every scan instance, one block and many."""
+    boards = sy.sample_board_pool(3, N, 2 * N, seed=100 + B)
+    weights = np.random.default_rng(100 + B).uniform(0.05, 0.95, 11)
+    env = sy.BatchedScotlandYardEnv(B, boards, P, 12, weights, seed=100 + B, reveal_interval=4)
+    graphs = [ol.OracleGraph(N, b.edge_links, b.edges.astype(np.int32)) for b in boards]
+    orc = ol.OracleBatch(graphs, env.env_graph_host, B, P, 12, node_stride=env.NS, weights=weights,
+                         tables=sy.reward_tables(), reveal_interval=4)
+    orc.reset(seed=100 + B)
+    rec = env.rollout(70)
+    ref = orc.rollout(70)
+    for k in ("pos", "t", "action", "terminated", "truncated", "winner", "mask", "reward"):
+        np.testing.assert_array_equal(_np(rec[k]), ref[k], err_msg=k)
+    np.testing.assert_array_equal(_np(rec["budget"]), ref["money"], err_msg="budget")
+    np.testing.assert_allclose(_np(rec["belief"]), ref["belief"], rtol=0, atol=BELIEF_TOL)
+    _compare_state(env, orc, "after an odd-batch rollout")
+    assert env.status() == 0
+    env.close()
+
+
 def test_rollout_equals_stepping_its_own_actions(sy):
     """Fused sampling path == caller-action path: replaying the recorded actions through step()."""
     boards = sy.sample_board_pool(2, 60, 100, seed=21)

@@ -79,7 +79,10 @@ def kernel_name(N, P, wpb, record, policy, max_degree):
     rec = "true" if record else "false"
     if wpb % 2 == 0 and nr <= 4 and A <= 2 * (64 // scan_w):
         if policy and A <= 64 // scan_w:
-            return f"sy::rollout3_kernel<{nr},true,{4 if pt == 4 else 0},true,0>", "move / helper pipeline, learned policy in the move wave"
+            md_x = 16 if (max_degree <= 0 or max_degree > 16) else max_degree
+            half = pt == 4 and (md_x + 5) // 6 <= 2          # 4 police: the half-wave scan (6 columns per agent, 2 per lane)
+            return (f"sy::rollout3_kernel<{nr},true,{4 if pt == 4 else 0},true,{2 if half else 0}>",
+                    "move / helper pipeline, learned policy in the move wave")
         if not policy:
             # the half-wave neighbour scan (launch_half_scan): columns per scan lane that cover the pool's widest row
             md_exact = 16 if (max_degree <= 0 or max_degree > 16) else max_degree

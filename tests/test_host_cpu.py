@@ -308,3 +308,23 @@ def test_optional_torchrl_registration_is_import_guarded():
         pytest.skip("torchrl present: the wrapper itself needs a GPU engine to construct")
     with pytest.raises(ImportError, match="torchrl"):
         t.make_torchrl_env(None)
+
+
+def test_bench_names_the_instance_the_launcher_picks():
+    """bench.py::kernel_name mirrors csrc/sy_kernels.hip::launch_engine_nr / launch_half_scan: the roofline object of
+    the bench line must name the kernel that really runs (rocprofv3's kernel trace is compared with it)."""
+    import bench
+    name = lambda *a: bench.kernel_name(*a)[0]
+    # headline: 5 agents, rows of at most 12 neighbours -> half-wave scan with 2 columns per lane
+    assert name(200, 4, 16, True, False, 10) == "sy::rollout3_kernel<4,true,4,false,2>"
+    assert name(200, 4, 16, True, False, 13) == "sy::rollout3_kernel<4,true,4,false,0>"      # wider rows: paired scan
+    assert name(200, 4, 16, False, False, 8) == "sy::rollout3_kernel<4,false,4,false,2>"
+    # 7 agents: 4 columns per agent and pass -> 3 columns per lane up to rows of 12, 4 up to 16 (boards of 129..256 nodes)
+    assert name(200, 6, 16, True, False, 10) == "sy::rollout3_kernel<4,true,6,false,3>"
+    assert name(200, 6, 16, True, False, 16) == "sy::rollout3_kernel<4,true,6,false,4>"
+    assert name(199, 5, 16, True, False, 10) == "sy::rollout3_kernel<4,true,5,false,2>"
+    assert name(199, 5, 16, True, False, 16) == "sy::rollout3_kernel<4,true,5,false,0>"
+    assert name(48, 6, 16, True, False, 9).startswith("sy::rollout3_kernel<1,true,6,false,0>")   # small boards: paired scan
+    # learned policy in the kernel
+    assert name(200, 4, 16, True, True, 8) == "sy::rollout3_kernel<4,true,4,true,2>"
+    assert name(200, 3, 16, True, True, 8) == "sy::rollout3_kernel<4,true,0,true,0>"

@@ -6,13 +6,13 @@ uniform-random policy, env kernels only.  One bench "step" = ONE fused rollout l
 of all B envs with the trajectory (obs, masks, belief, actions, rewards, flags) recorded to HBM.
 E=400 edges and money=20 are SURVEY.md section 8 choices (BASELINE gives neither).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Timing: W untimed warm-up steps, then R >= 5 repeats of EXACTLY K steps, each repeat bracketed by a barrier +
 `torch.cuda.synchronize()` on both sides and reduced with MAX over ranks; the line reports the MEDIAN repeat (min /
-max beside it).  R is chosen so that the timed regions add up to >= ~120 ms.  No launches precede the warm-up: the
+max beside it).  R is chosen so that the timed regions add up to >= ~1.6 s (--timed-seconds).  No launches precede the warm-up: the
 clock / power transient of an idle device (its first ~8 ms under load) falls into the first repeat and the median
 ignores it.  Kernel time = HIP events on the launch stream around every timed launch (median).
 
@@ -20,7 +20,7 @@ Episodes are independent: ranks own disjoint env shards (weak scaling, B per GPU
 the rollout.  The ONE exchange of the multi-GPU path — the trajectory all-gather at the PPO update, BASELINE
 configs[3] — is timed separately for N > 1 (`gather`: zero-copy `collector.TrajectoryExchange`).
 Rank 0 prints ONE JSON line with `roofline` (HBM), `cpu_baseline` (the CPU oracle, a port: all-core and one-thread)
-and `verified` (the last timed trajectory checked against the oracle, outside the timed region).
+and `verified` (the launch right after the timed region checked against the oracle).
 """
 import argparse
 import json
@@ -67,43 +67,60 @@ def usable_cores():
     return n
 
 
-def kernel_name(N, P, wpb, record, policy, max_degree):
-    """The instance the launcher picks (csrc/sy_kernels.hip::launch_engine_nr) for this configuration."""
-    nr = (N + 63) // 64
-    nr = 1 if nr <= 1 else 2 if nr <= 2 else 4 if nr <= 4 else 8 if nr <= 8 else 16
-    pt = P if P in (2, 4, 5, 6) else 0
-    A = P + 1
-    md = 16 if (max_degree <= 0 or max_degree > 16) else max(8, max_degree)        # sy_capi.hip::sy_env_set_graph_pool
-    coarse = 8 if md <= 8 else (12 if md <= 12 else 16)
-    scan_w = md if (A > 64 // coarse and 64 // md > 64 // coarse) else coarse
-    rec = "true" if record else "false"
-    if wpb % 2 == 0 and nr <= 4 and A <= 2 * (64 // scan_w):
-        if policy and A <= 64 // scan_w:
-            md_x = 16 if (max_degree <= 0 or max_degree > 16) else max_degree
-            half = pt == 4 and (md_x + 5) // 6 <= 2          # 4 police: the half-wave scan (6 columns per agent, 2 per lane)
-            return (f"sy::rollout3_kernel<{nr},true,{4 if pt == 4 else 0},true,{2 if half else 0}>",
-                    "move / helper pipeline, learned policy in the move wave")
-        if not policy:
-            # the half-wave neighbour scan (launch_half_scan): columns per scan lane that cover the pool's widest row
-            md_exact = 16 if (max_degree <= 0 or max_degree > 16) else max_degree
-            gw = min(16, 32 // A)
-            need = (md_exact + gw - 1) // gw
-            cols = need if (A <= 7 and need * gw <= 32) else 0
-            hs = 0
-            if cols > 0 and 1 <= pt <= 4 and cols <= 2:
-                hs = 2
-            elif cols > 0 and nr == 4 and pt in (5, 6):
-                c0 = 2 if pt == 5 else 3
-                hs = c0 if cols <= c0 else (c0 + 1 if cols <= c0 + 1 else 0)
-            if hs:
-                return (f"sy::rollout3_kernel<{nr},{rec},{pt},false,{hs}>",
-                        f"move / helper pipeline: paired move waves (half-wave scan, {hs} columns per lane) + helper waves")
-            return f"sy::rollout3_kernel<{nr},{rec},{pt},false,0>", "move / helper pipeline: paired move waves + helper waves"
-    if wpb % 2 == 0:
-        if policy:
-            return f"sy::rollout2_kernel<{nr},true,{4 if pt == 4 else 0},true>", "paired move waves + belief waves"
-        return f"sy::rollout2_kernel<{nr},{rec},{pt},false>", "paired move waves + belief waves"
-    return f"sy::rollout_kernel<{nr},{rec},{pt}>", "one move wave per episode + belief waves"
+def free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def rank_environment(rank, world, port, base=None):
+    """Environment of rank `rank` of a one-node job: what torch.distributed.run would set."""
+    env = dict(os.environ if base is None else base)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this pool
+    return env
+
+
+def spawn_ranks(n, argv, popen=None, timeout=None):
+    """`python bench.py --gpus N` without a launcher: THIS process — which has not touched the GPU (no torch import, no
+    HIP call; a process that has must never exec or fork GPU work) — starts the N ranks as child processes with the
+    environment torch.distributed.run would give them, relays rank 0's single JSON line and returns the worst exit
+    code.  If a rank fails, the others are stopped (by their own PIDs)."""
+    import subprocess
+    popen = popen or subprocess.Popen
+    port = free_port()
+    procs = []
+    for r in range(n):
+        procs.append(popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=rank_environment(r, n, port),
+                           stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, stderr=None))
+    t_end = None if timeout is None else time.time() + timeout
+    worst, out0 = 0, b""
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            try:
+                if r == 0:
+                    o, _ = procs[0].communicate(timeout=0.2)
+                    out0 += o or b""
+                    rc = procs[0].returncode
+                else:
+                    rc = procs[r].wait(timeout=0.2)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                worst = worst or rc
+                for q in pending:          # a collective with a dead peer never returns: stop the others
+                    procs[q].terminate()
+        if t_end is not None and time.time() > t_end and pending:
+            for q in pending:
+                procs[q].kill()
+            worst = worst or 124
+    sys.stdout.write(out0.decode("utf-8", "replace"))
+    sys.stdout.flush()
+    return worst
 
 
 def make_oracle(args, boards, weights, env_graph, threads, env_id_offset=0):
@@ -175,7 +192,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--repeats", type=int, default=0, help="timed repeats of K steps (0 = at least 5, enough for ~120 ms)")
+    ap.add_argument("--repeats", type=int, default=0, help="timed repeats of K steps (0 = at least 5, enough for --timed-seconds)")
+    ap.add_argument("--timed-seconds", type=float, default=1.6, help="target for the sum of the timed regions when --repeats is 0")
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--nodes", type=int, default=200)
     ap.add_argument("--edges", type=int, default=400)
@@ -194,7 +212,12 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the oracle check of the last timed trajectory")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the separately timed trajectory all-gather")
     ap.add_argument("--step-api", action="store_true", help="also time the per-step sy_env_step launch path")
+    ap.add_argument("--no-config3", action="store_true", help="skip the configs[2] sub-record (learned policy + update)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: start the ranks ourselves, BEFORE anything touches the GPU
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -214,9 +237,6 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group(backend=backend)
-    elif args.gpus > 1:
-        print("launch with torch.distributed.run for --gpus > 1", file=sys.stderr)
-        sys.exit(2)
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
 
@@ -246,29 +266,40 @@ def main():
         one_step()
     sync_all()
     est_step = max((time.perf_counter() - tw) / max(args.warmup, 1), 1e-5)
-    repeats = args.repeats if args.repeats > 0 else int(min(50, max(5, np.ceil(0.12 / (K * est_step)))))
-    if world > 1:      # every rank must run the same number of repeats
-        rr = torch.tensor([repeats], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
-        dist.all_reduce(rr, op=dist.ReduceOp.MAX)
-        repeats = int(rr.item())
+    repeats = args.repeats        # 0: decided after the first timed repeat (see below)
 
     state_names = ("pos", "budget", "t", "step_count", "_visits", "_belief", "_mask")
-    snap = None
     elapsed, events = [], []
-    for r in range(repeats):
+    r = 0
+    while True:
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(K)]
         sync_all()
         t0 = time.perf_counter()
         for i in range(K):
-            if do_verify and r == repeats - 1 and i == K - 1:
-                # snapshot of the live state (7 small device copies, ~10 MB) just before the LAST timed launch
-                snap = {n.lstrip("_"): getattr(env, n).clone() for n in state_names if getattr(env, n) is not None}
             ev[i][0].record()   # the engine launches on torch's current stream, so these bracket the kernel
             one_step()
             ev[i][1].record()
         sync_all()
         elapsed.append(time.perf_counter() - t0)
         events.append(ev)
+        r += 1
+        if repeats <= 0:
+            # enough repeats for >= --timed-seconds of timed launches (a device sampler with a period of seconds then
+            # sees the load), at least 5, decided from the first timed repeat; every rank must run the same number
+            repeats = int(min(2000, max(5, np.ceil(args.timed_seconds / max(elapsed[0], 1e-5)))))
+            if world > 1:
+                rr = torch.tensor([repeats], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
+                dist.all_reduce(rr, op=dist.ReduceOp.MAX)
+                repeats = int(rr.item())
+        if r >= repeats:
+            break
+    # the launch the oracle replays: one more step of the same stream of launches, right after the timed region
+    # (untimed, so that the state snapshot — 7 device copies, ~10 MB — is in nobody's measurement)
+    snap = None
+    if do_verify:
+        snap = {n.lstrip("_"): getattr(env, n).clone() for n in state_names if getattr(env, n) is not None}
+        one_step()
+        torch.cuda.synchronize(device)     # (rank 0 only: no barrier here)
     env.check_status()          # a launch that lost a hand-off reports it here instead of returning wrong data
     el = torch.tensor(elapsed, dtype=torch.float64, device=device if (world > 1 and backend == "nccl") else "cpu")
     if world > 1:
@@ -285,14 +316,20 @@ def main():
     achieved = bytes_per_launch / (kern_ms * 1e-3) / 1e9
     traffic, traffic_source = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")   # measured by tools/pmc_traffic.py under rocprofv3
+    build_id = sy._lib.build_id()
     if os.path.exists(pmc):
         try:
             with open(pmc) as f:
                 rec = json.load(f)
             if full and rec.get("config") == {"nodes": N, "police": P, "envs": B, "fused": T}:
-                traffic = rec.get("hbm_bytes_per_launch")
-                traffic_source = ("stored: profiles/pmc_traffic.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                  "this workload, gfx950 x2 fetch correction; not measured in this run)")
+                if rec.get("build_id") == build_id:
+                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = ("stored: profiles/pmc_traffic.json, collected from this library build (%s) in separate rocprofv3 "
+                                      "--pmc FETCH_SIZE / WRITE_SIZE passes of this workload, gfx950 x2 fetch correction; not "
+                                      "measured in this run" % build_id)
+                else:      # counters of another kernel are not this kernel's traffic
+                    traffic_source = ("none: profiles/pmc_traffic.json was collected from library build %s, this run loaded %s"
+                                      % (rec.get("build_id"), build_id))
         except Exception:
             traffic = None
 
@@ -315,7 +352,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "hbm_frac_measured": (traffic / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                     "kernel": "%s (fused rollout: %s)" % kernel_name(N, P, env.waves_per_block, not args.no_record, False, env.max_degree),
+                     "kernel": env.rollout_kernel_name(record=not args.no_record), "library_build_id": build_id,
                      "kernel_ms": kern_ms, "kernel_ms_min": float(kern.min()), "kernel_ms_max": float(kern.max()),
                      "algorithmic_bytes_per_env_step": R + W, "algorithmic_read_bytes_per_env_step": R,
                      "read_only_frac": (R * T * B / (kern_ms * 1e-3) / 1e9) / HBM_PEAK_GBS,
@@ -325,7 +362,7 @@ def main():
     if do_verify and snap is not None:
         ok, worst, n_done = verify_last_launch(args, boards, weights, env, snap, out, T)
         result["verified"] = ok
-        result["verification"] = {"what": "last timed launch replayed by the CPU oracle from a state snapshot: record "
+        result["verification"] = {"what": "the launch that follows the last timed one (same stream of launches, untimed) replayed by the CPU oracle from a state snapshot: record "
                                           "(pos, budget, t, action, flags, winner, float64 reward, masks) and live state "
                                           "bit-exact, belief max abs diff", "belief_max_abs_diff": worst,
                                   "episodes_finished_in_launch": n_done}

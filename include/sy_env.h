@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SY_ABI_VERSION 4
+#define SY_ABI_VERSION 5
 #define SY_ELL_WIDTH 16
 #define SY_MAX_AGENTS 8
 #define SY_MAX_NODES 1024
@@ -125,6 +125,9 @@ typedef struct sy_mappo_weights {
 int sy_record_words(int32_t num_agents);
 
 int sy_abi_version(void);
+/* digest of the sources this library was built from (student_mechanism_design_amd/build.py::source_digest): stored
+ * profiles carry it, so a benchmark can tell whether a counter file belongs to the library it runs */
+const char *sy_build_id(void);
 const char *sy_last_error(void);
 
 /* replaces CustomEnvironment.__init__ (yard.py:18-78) for a batch of B envs */
@@ -132,6 +135,11 @@ int sy_env_create(const sy_env_config *cfg, sy_env **out);
 int sy_env_destroy(sy_env *env);
 /* LDS bytes and block count one engine launch uses (for DESIGN/bench reporting) */
 int sy_env_launch_info(const sy_env *env, int32_t *waves_per_block, int32_t *blocks, int32_t *lds_bytes);
+
+/* the kernel instance sy_env_rollout will launch for this handle as configured NOW (graph pool, policy, state
+ * bound), e.g. "sy::rollout3_kernel<4,true,4,false,2>": the name rocprofv3 reports, so a benchmark can name the
+ * kernel it measured without mirroring the launcher's rules.  `record` != 0: with a trajectory record. */
+int sy_env_rollout_kernel_name(const sy_env *env, int32_t record, char *buf, int32_t buf_len);
 
 /* board + shortest-path tables (replaces board.edge_links/edges yard.py:91-93 and Pathfinder.set_board
  * pathfinding.py:25-32); all device pointers.  max_degree is the widest ELL row of the pool: it sizes the neighbour

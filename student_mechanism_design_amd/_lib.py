@@ -11,7 +11,7 @@ MAX_AGENTS = 8
 MAX_NODES = 1024
 NUM_WEIGHTS = 11
 MRX_MONEY = 1000
-ABI_VERSION = 4
+ABI_VERSION = 5
 STATUS_BELIEF_WAIT_EXPIRED = 1
 STATUS_RING_WAIT_EXPIRED = 2
 
@@ -56,7 +56,7 @@ EXPORTS = ["sy_abi_version", "sy_record_words", "sy_last_error", "sy_env_create"
            "sy_env_set_graph_pool", "sy_env_set_rewards", "sy_env_set_policy", "sy_env_bind_state", "sy_env_reset", "sy_env_reset_to",
            "sy_env_step", "sy_env_step_record", "sy_env_rollout", "sy_action_mask_dense", "sy_belief_update", "sy_build_apsp", "sy_sample_boards",
            "sy_masked_categorical_sample", "sy_mappo_policy_act", "sy_env_bind_status", "sy_env_status",
-           "sy_returns_advantages"]
+           "sy_returns_advantages", "sy_build_id", "sy_env_rollout_kernel_name"]
 
 _lib = None
 
@@ -74,6 +74,8 @@ def load():
     vp, i32, u64 = C.c_void_p, C.c_int32, C.c_uint64
     lib.sy_abi_version.restype = C.c_int
     lib.sy_last_error.restype = C.c_char_p
+    lib.sy_build_id.restype = C.c_char_p
+    lib.sy_env_rollout_kernel_name.argtypes = [vp, i32, C.c_char_p, i32]
     lib.sy_record_words.argtypes = [i32]
     lib.sy_env_create.argtypes = [C.POINTER(EnvConfig), C.POINTER(vp)]
     lib.sy_env_destroy.argtypes = [vp]
@@ -98,12 +100,17 @@ def load():
     lib.sy_mappo_policy_act.argtypes = [vp, vp, C.c_int64, C.POINTER(MappoWeights), i32, i32, i32, i32, u64, u64, vp, vp, vp, vp, vp, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("sy_last_error",):
+        if name not in ("sy_last_error", "sy_build_id"):
             fn.restype = C.c_int
     if lib.sy_abi_version() != ABI_VERSION:
         raise EngineError(f"libsy_env.so ABI {lib.sy_abi_version()} != expected {ABI_VERSION}; rebuild it")
     _lib = lib
     return lib
+
+
+def build_id() -> str:
+    """Digest of the sources the loaded library was built from (sy_build_id)."""
+    return load().sy_build_id().decode()
 
 
 def check(rc, what=""):

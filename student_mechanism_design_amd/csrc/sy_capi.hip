@@ -33,7 +33,11 @@ constexpr size_t kMaxLds = 160 * 1024;
 
 extern "C" {
 
+#ifndef SY_BUILD_ID
+#define SY_BUILD_ID "unstamped"
+#endif
 int sy_abi_version(void) { return SY_ABI_VERSION; }
+const char* sy_build_id(void) { return SY_BUILD_ID; }
 int sy_record_words(int32_t num_agents) { return (5 * num_agents + 4 + 3) & ~3; }
 const char* sy_last_error(void) { return g_err; }
 
@@ -122,6 +126,14 @@ int sy_env_launch_info(const sy_env* env, int32_t* wpb, int32_t* blocks, int32_t
     return SY_OK;
 }
 
+int sy_env_rollout_kernel_name(const sy_env* env, int32_t record, char* buf, int32_t buf_len) {
+    if (!env || !buf || buf_len < 1) return fail(SY_ERR_INVALID, "sy_env_rollout_kernel_name: null argument%s");
+    if (!env->has_graph) return fail(SY_ERR_STATE, "%s: call sy_env_set_graph_pool first", "sy_env_rollout_kernel_name");
+    const sy::RolloutPlan pl = sy::plan_rollout(env->p, record != 0, env->wpb, env->lds);
+    sy::rollout_plan_name(pl, buf, (size_t)buf_len);
+    return SY_OK;
+}
+
 int sy_env_set_graph_pool(sy_env* env, const uint32_t* ell, const uint16_t* apsp, const float* inv_deg,
                           const int32_t* env_graph, int32_t max_degree) {
     if (!env || !ell || !apsp || !inv_deg || !env_graph) return fail(SY_ERR_INVALID, "sy_env_set_graph_pool: null argument%s");
@@ -167,15 +179,20 @@ int sy_env_set_policy(sy_env* env, const sy_mappo_weights* w, int32_t hidden) {
         return SY_OK;
     }
     if (!w->w1t || !w->b1 || !w->w2 || !w->b2) return fail(SY_ERR_INVALID, "sy_env_set_policy: w1t, b1, w2, b2 are required%s");
-    const bool pipeline_ok = env->p.N <= 256 && (env->wpb & 1) == 0;      // sy_kernels.hip::launch_engine_nr picks rollout3 then
-    const int hmax = pipeline_ok ? 128 : 64;
-    if (hidden < 4 || hidden > hmax || (hidden & 3))
-        return fail(SY_ERR_INVALID, "sy_env_set_policy: hidden must be a multiple of 4, at most 128 (64 on boards of more than 256 nodes)%s");
+    if (!env->has_graph) return fail(SY_ERR_STATE, "%s: call sy_env_set_graph_pool first (the board decides the kernel instance)", "sy_env_set_policy");
+    if ((env->wpb & 1) != 0) return fail(SY_ERR_INVALID, "sy_env_set_policy: needs an even waves_per_block%s");
+    if (hidden < 4 || (hidden & 3)) return fail(SY_ERR_INVALID, "sy_env_set_policy: hidden must be a multiple of 4, at least 4%s");
+    // the limits are those of the instance that will run (sy_dispatch.hip::plan_rollout — the launcher reads the same plan)
+    const sy::RolloutPlan pl = sy::plan_rollout(env->p, true, env->wpb, env->lds, hidden);
+    const int hmax = pl.family == 3 ? 128 : 64;
+    if (!pl.pol) return fail(SY_ERR_INVALID, "sy_env_set_policy: no policy instance for this configuration%s");
+    if (hidden > hmax)
+        return fail(SY_ERR_INVALID, "sy_env_set_policy: hidden must be at most %s%lld for this configuration (128 on the pipeline kernel: "
+                    "boards of up to 256 nodes, max_timestep < 2^20 - 2; 64 otherwise)", "", hmax);
     if ((reinterpret_cast<uintptr_t>(w->w2) & 15) || (reinterpret_cast<uintptr_t>(w->w1t) & 15))
         return fail(SY_ERR_INVALID, "sy_env_set_policy: weights must be 16-byte aligned%s");
-    if ((env->wpb & 1) != 0) return fail(SY_ERR_INVALID, "sy_env_set_policy: needs an even waves_per_block%s");
-    const int pslice = pipeline_ok ? env->p.A * hidden * 4 + 128 : SY_POLICY_SLICE;
-    if (env->lds + (size_t)env->wpb * pslice > kMaxLds)
+    const int pslice = pl.pslice;
+    if (pl.lds > kMaxLds)
         return fail(SY_ERR_INVALID, "sy_env_set_policy: no LDS left for the policy scratch (use a smaller waves_per_block)%s");
     env->p.pw1t = w->w1t; env->p.pb1 = w->b1; env->p.pw2 = w->w2; env->p.pb2 = w->b2;
     env->p.pbound = w->logit_bound;
@@ -251,7 +268,7 @@ int sy_env_step(sy_env* env, const int32_t* actions, void* stream) {
     if (!actions) return fail(SY_ERR_INVALID, "sy_env_step: null actions%s");
     sy_rollout_buffers none;
     std::memset(&none, 0, sizeof(none));
-    hipError_t e = sy::launch_engine(env->p, actions, 1, none, true, env->blocks, env->wpb, env->lds, (hipStream_t)stream);
+    hipError_t e = sy::launch_step(env->p, actions, none, env->blocks, env->wpb, env->lds, (hipStream_t)stream);
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_env_step launch");
 }
 
@@ -262,7 +279,7 @@ int sy_env_step_record(sy_env* env, const int32_t* actions, const sy_rollout_buf
     if (!actions || !row) return fail(SY_ERR_INVALID, "sy_env_step_record: null argument%s");
     if ((reinterpret_cast<uintptr_t>(row->mask) & 15) || (reinterpret_cast<uintptr_t>(row->record) & 15))
         return fail(SY_ERR_INVALID, "sy_env_step_record: record / mask rows must be 16-byte aligned%s");
-    hipError_t e = sy::launch_engine(env->p, actions, 1, *row, true, env->blocks, env->wpb, env->lds, (hipStream_t)stream);
+    hipError_t e = sy::launch_step(env->p, actions, *row, env->blocks, env->wpb, env->lds, (hipStream_t)stream);
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_env_step_record launch");
 }
 
@@ -280,8 +297,12 @@ int sy_env_rollout(sy_env* env, int32_t T, const sy_rollout_buffers* out, void* 
     if (env->p.pw2) {       // learned policy in the kernel: recorded rollouts on single-pass boards
         if (!o.record) return fail(SY_ERR_INVALID, "sy_env_rollout: a policy rollout needs a record%s");
         if (env->p.A > 64 / env->p.scan_w) return fail(SY_ERR_INVALID, "sy_env_rollout: the in-kernel policy needs boards whose agents fit one scan pass%s");
+        // the instance is chosen per launch: a board pool bound after sy_env_set_policy may have moved it
+        const sy::RolloutPlan pl = sy::plan_rollout(env->p, true, env->wpb, env->lds);
+        if (!pl.pol || pl.pslice != env->p.pslice || env->p.pH > (pl.family == 3 ? 128 : 64) || pl.lds > kMaxLds)
+            return fail(SY_ERR_STATE, "%s: the policy was set for another board pool; call sy_env_set_policy again", "sy_env_rollout");
     }
-    hipError_t e = sy::launch_engine(env->p, nullptr, T, o, false, env->blocks, env->wpb, env->lds, (hipStream_t)stream);
+    hipError_t e = sy::launch_rollout(env->p, T, o, env->blocks, env->wpb, env->lds, (hipStream_t)stream);
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_env_rollout launch");
 }
 

@@ -45,8 +45,38 @@ struct EngineParams {
 };
 #define SY_POLICY_SLICE 2304      // per-episode LDS scratch of the in-kernel policy: 8 hidden vectors of 64 floats + slots
 
-hipError_t launch_engine(const EngineParams& p, const int32_t* actions, int T, const sy_rollout_buffers& out, bool ext,
-                         int blocks, int wpb, size_t lds, hipStream_t stream);
+// ---- the fused rollout: which kernel instance a configuration runs on (sy_dispatch.hip) ------------------------------
+// One place decides it — the launcher, sy_env_set_policy's limits and sy_env_rollout_kernel_name all read this plan.
+// ELL columns per agent of the half-wave neighbour scan (one episode per half wave: 32 lanes / agents)
+__host__ __device__ constexpr int half_scan_gw(int P) { return 32 / (P + 1) > SY_ELL_WIDTH ? SY_ELL_WIDTH : 32 / (P + 1); }
+
+struct RolloutPlan {
+    int family;        // 3 = rollout3_kernel (move / helper pipeline), 2 = rollout2_kernel (paired move waves + belief
+                       // waves), 1 = rollout_kernel (one episode per move wave, odd block sizes)
+    int nr;            // belief slabs of 64 nodes the instance is compiled for: 1, 2, 4, 8, 16
+    int pt;            // police count fixed at compile time (2, 4, 5, 6) or 0 = generic
+    int hs;            // rollout3: columns per lane of the half-wave neighbour scan, 0 = paired scan
+    bool rec, pol;     // trajectory recorded; actions from the MAPPO actors (sy_env_set_policy)
+    int threads;       // block size
+    size_t lds;        // dynamic LDS bytes of the launch (board + episode slices + policy scratch)
+    int pslice;        // per-episode LDS scratch of the in-kernel policy on this family (0 without a policy)
+};
+// `policy_hidden` > 0 asks for the plan WITH a policy of that hidden size even if none is set yet (sy_env_set_policy
+// validates its argument against the instance that would run); 0 = use p.pw2 / p.pH as they are.
+RolloutPlan plan_rollout(const EngineParams& p, bool record, int wpb, size_t lds_base, int policy_hidden = 0);
+void rollout_plan_name(const RolloutPlan& pl, char* buf, size_t n);     // e.g. "sy::rollout3_kernel<4,true,4,false,2>"
+int rollout_policy_slice(int family, int A, int hidden);
+
+hipError_t launch_rollout(const EngineParams& p, int T, const sy_rollout_buffers& out, int blocks, int wpb, size_t lds,
+                          hipStream_t stream);
+hipError_t launch_step(const EngineParams& p, const int32_t* actions, const sy_rollout_buffers& rec, int blocks, int wpb, size_t lds,
+                       hipStream_t stream);
+// instance groups (one translation unit each); false = the planned instance is not in that unit
+#define SY_DECL_GROUP(name) bool name(const RolloutPlan& pl, const EngineParams& p, int T, const sy_rollout_buffers& out, int blocks, hipStream_t stream)
+SY_DECL_GROUP(launch_r3_a); SY_DECL_GROUP(launch_r3_b); SY_DECL_GROUP(launch_r3_c); SY_DECL_GROUP(launch_r3_d); SY_DECL_GROUP(launch_r3_p);
+SY_DECL_GROUP(launch_r2_a); SY_DECL_GROUP(launch_r2_b); SY_DECL_GROUP(launch_r2_c);
+SY_DECL_GROUP(launch_r1_a); SY_DECL_GROUP(launch_r1_b);
+#undef SY_DECL_GROUP
 hipError_t launch_reset(const EngineParams& p, const uint8_t* env_sel, const int32_t* starts, int zero_count, int blocks,
                         int wpb, size_t lds, hipStream_t stream);
 hipError_t launch_action_mask_dense(const double* adj, const double* wts, const double* tolls, int N, const int32_t* cur,

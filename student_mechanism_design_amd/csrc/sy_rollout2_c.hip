@@ -1,0 +1,41 @@
+// sy_rollout2_c.hip — rollout2 instances: boards of 257..1024 nodes
+// (instance list generated once; add an instance here AND in sy_dispatch.cpp::plan_rollout)
+#include "sy_rollout_legacy.hpp"
+
+namespace sy {
+
+template <int NR, bool REC, int PT, bool POL>
+static bool try_launch(const RolloutPlan& pl, const EngineParams& p, int T, const sy_rollout_buffers& out, int blocks, hipStream_t stream) {
+    if (pl.nr != NR || pl.rec != REC || pl.pt != PT || pl.pol != POL) return false;
+    hipLaunchKernelGGL((rollout2_kernel<NR, REC, PT, POL>), dim3(blocks), dim3(pl.threads), pl.lds, stream, p, T, out);
+    return true;
+}
+
+bool launch_r2_c(const RolloutPlan& pl, const EngineParams& p, int T, const sy_rollout_buffers& out, int blocks, hipStream_t stream) {
+    return try_launch<8, true, 0, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<8, true, 2, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<8, true, 4, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<8, true, 5, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<8, true, 6, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<8, false, 0, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<8, false, 2, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<8, false, 4, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<8, false, 5, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<8, false, 6, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<16, true, 0, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<16, true, 2, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<16, true, 4, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<16, true, 5, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<16, true, 6, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<16, false, 0, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<16, false, 2, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<16, false, 4, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<16, false, 5, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<16, false, 6, false>(pl, p, T, out, blocks, stream) ||
+           try_launch<8, true, 4, true>(pl, p, T, out, blocks, stream) ||
+           try_launch<8, true, 0, true>(pl, p, T, out, blocks, stream) ||
+           try_launch<16, true, 4, true>(pl, p, T, out, blocks, stream) ||
+           try_launch<16, true, 0, true>(pl, p, T, out, blocks, stream);
+}
+
+}  // namespace sy

@@ -1,0 +1,28 @@
+// sy_rollout3_a.hip — rollout3 instances: boards of 129..256 nodes, trajectory recorded (the headline instance lives here)
+// (instance list generated once; add an instance here AND in sy_dispatch.cpp::plan_rollout)
+#include "sy_rollout3.hpp"
+
+namespace sy {
+
+template <int NR, bool REC, int PT, bool POL, int HS>
+static bool try_launch(const RolloutPlan& pl, const EngineParams& p, int T, const sy_rollout_buffers& out, int blocks, hipStream_t stream) {
+    if (pl.nr != NR || pl.rec != REC || pl.pt != PT || pl.pol != POL || pl.hs != HS) return false;
+    hipLaunchKernelGGL((rollout3_kernel<NR, REC, PT, POL, HS>), dim3(blocks), dim3(pl.threads), pl.lds, stream, p, T, out);
+    return true;
+}
+
+bool launch_r3_a(const RolloutPlan& pl, const EngineParams& p, int T, const sy_rollout_buffers& out, int blocks, hipStream_t stream) {
+    return try_launch<4, true, 0, false, 0>(pl, p, T, out, blocks, stream) ||
+           try_launch<4, true, 2, false, 0>(pl, p, T, out, blocks, stream) ||
+           try_launch<4, true, 4, false, 0>(pl, p, T, out, blocks, stream) ||
+           try_launch<4, true, 5, false, 0>(pl, p, T, out, blocks, stream) ||
+           try_launch<4, true, 6, false, 0>(pl, p, T, out, blocks, stream) ||
+           try_launch<4, true, 2, false, 2>(pl, p, T, out, blocks, stream) ||
+           try_launch<4, true, 4, false, 2>(pl, p, T, out, blocks, stream) ||
+           try_launch<4, true, 5, false, 2>(pl, p, T, out, blocks, stream) ||
+           try_launch<4, true, 5, false, 3>(pl, p, T, out, blocks, stream) ||
+           try_launch<4, true, 6, false, 3>(pl, p, T, out, blocks, stream) ||
+           try_launch<4, true, 6, false, 4>(pl, p, T, out, blocks, stream);
+}
+
+}  // namespace sy

@@ -237,6 +237,14 @@ class BatchedScotlandYardEnv:
             self._status.zero_()
             raise _lib.EngineError(msg)
 
+    def rollout_kernel_name(self, record: bool = True) -> str:
+        """The kernel instance `rollout` launches for this env as configured now (what rocprofv3 reports): asked from
+        the library (`sy_env_rollout_kernel_name`), which owns the selection rules."""
+        buf = C.create_string_buffer(128)
+        _lib.check(self.lib.sy_env_rollout_kernel_name(self._handle, 1 if record else 0, buf, len(buf)),
+                   "sy_env_rollout_kernel_name")
+        return buf.value.decode()
+
     def set_reward_weights(self, reward_weights):
         """The 11 weights of reward_calculator.py (RewardWeightNet output, reward_net.py:5-17)."""
         self.reward_weights = weights_to_array(reward_weights)

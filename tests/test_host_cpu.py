@@ -3,6 +3,8 @@ loud-failure rule of the product path."""
 import ctypes as C
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -310,11 +312,37 @@ def test_optional_torchrl_registration_is_import_guarded():
         t.make_torchrl_env(None)
 
 
-def test_bench_names_the_instance_the_launcher_picks():
-    """bench.py::kernel_name mirrors csrc/sy_kernels.hip::launch_engine_nr / launch_half_scan: the roofline object of
-    the bench line must name the kernel that really runs (rocprofv3's kernel trace is compared with it)."""
-    import bench
-    name = lambda *a: bench.kernel_name(*a)[0]
+def _host_only_env(N, P, max_degree, wpb=0, max_t=250, B=4096):
+    """An engine handle configured on the host only (fake, never dereferenced device pointers; nothing is launched)."""
+    lib = sy._lib.load()
+    h = C.c_void_p()
+    NS = (N + 15) // 16 * 16
+    assert lib.sy_env_create(C.byref(sy._lib.EnvConfig(B, N, P, 20, max_t, 1, NS, 5, 0, 0, 1, wpb, 0)), C.byref(h)) == 0, \
+        lib.sy_last_error()
+    fake = C.c_void_p(0x10000)
+    assert lib.sy_env_set_graph_pool(h, fake, fake, fake, fake, max_degree) == 0
+    return lib, h
+
+
+def _kernel_name(lib, h, record=True):
+    buf = C.create_string_buffer(128)
+    assert lib.sy_env_rollout_kernel_name(h, 1 if record else 0, buf, len(buf)) == 0
+    return buf.value.decode()
+
+
+def test_library_names_the_instance_the_launcher_picks():
+    """sy_env_rollout_kernel_name reads the plan the launcher itself uses (csrc/sy_dispatch.hip::plan_rollout): the
+    roofline object of the bench line names the kernel that really runs (rocprofv3's kernel trace is compared with it)."""
+    def name(N, P, wpb, record, policy, max_degree, hidden=64, max_t=250):
+        lib, h = _host_only_env(N, P, max_degree, wpb=wpb, max_t=max_t)
+        try:
+            if policy:
+                fake = 0x10000
+                w = sy._lib.MappoWeights(*([fake] * 10))
+                assert lib.sy_env_set_policy(h, C.byref(w), hidden) == 0, lib.sy_last_error()
+            return _kernel_name(lib, h, record)
+        finally:
+            lib.sy_env_destroy(h)
     # headline: 5 agents, rows of at most 12 neighbours -> half-wave scan with 2 columns per lane
     assert name(200, 4, 16, True, False, 10) == "sy::rollout3_kernel<4,true,4,false,2>"
     assert name(200, 4, 16, True, False, 13) == "sy::rollout3_kernel<4,true,4,false,0>"      # wider rows: paired scan
@@ -324,7 +352,93 @@ def test_bench_names_the_instance_the_launcher_picks():
     assert name(200, 6, 16, True, False, 16) == "sy::rollout3_kernel<4,true,6,false,4>"
     assert name(199, 5, 16, True, False, 10) == "sy::rollout3_kernel<4,true,5,false,2>"
     assert name(199, 5, 16, True, False, 16) == "sy::rollout3_kernel<4,true,5,false,0>"
-    assert name(48, 6, 16, True, False, 9).startswith("sy::rollout3_kernel<1,true,6,false,0>")   # small boards: paired scan
+    assert name(48, 6, 16, True, False, 9) == "sy::rollout3_kernel<1,true,6,false,0>"         # small boards: paired scan
+    # odd block sizes / boards of more than 256 nodes: the round-1 kernels
+    assert name(200, 4, 7, True, False, 10) == "sy::rollout_kernel<4,true,4>"
+    assert name(520, 2, 0, True, False, 10, ) == "sy::rollout2_kernel<16,true,2,false>"
     # learned policy in the kernel
     assert name(200, 4, 16, True, True, 8) == "sy::rollout3_kernel<4,true,4,true,2>"
     assert name(200, 3, 16, True, True, 8) == "sy::rollout3_kernel<4,true,0,true,0>"
+
+
+def test_policy_limits_follow_the_instance_that_runs():
+    """sy_env_set_policy and the launcher read ONE plan.  With max_timestep >= 2^20 - 2 the pipeline kernel is
+    not eligible (its ring packs the timestep into 20 bits), the round-1 kernel runs the policy with its fixed 2304-byte
+    scratch, and a hidden size of 128 would not fit: it must be refused, not accepted with overlapping slices."""
+    fake = 0x10000
+    w = sy._lib.MappoWeights(*([fake] * 10))
+    lib, h = _host_only_env(200, 4, 8, max_t=1 << 20)
+    try:
+        assert lib.sy_env_set_policy(h, C.byref(w), 128) == -1 and b"at most 64" in lib.sy_last_error()
+        assert lib.sy_env_set_policy(h, C.byref(w), 64) == 0
+        assert _kernel_name(lib, h) == "sy::rollout2_kernel<4,true,4,true>"
+    finally:
+        lib.sy_env_destroy(h)
+    lib, h = _host_only_env(200, 4, 8)
+    try:
+        assert lib.sy_env_set_policy(h, C.byref(w), 128) == 0
+        assert _kernel_name(lib, h) == "sy::rollout3_kernel<4,true,4,true,2>"
+        assert lib.sy_env_set_policy(h, C.byref(w), 132) == -1
+        assert lib.sy_env_set_policy(h, None, 0) == 0 and _kernel_name(lib, h) == "sy::rollout3_kernel<4,true,4,false,2>"
+    finally:
+        lib.sy_env_destroy(h)
+    # odd block sizes have no policy instance; a handle without a board pool cannot be planned yet
+    lib, h = _host_only_env(200, 4, 8, wpb=7)
+    try:
+        assert lib.sy_env_set_policy(h, C.byref(w), 64) == -1
+    finally:
+        lib.sy_env_destroy(h)
+    h2 = C.c_void_p()
+    assert lib.sy_env_create(C.byref(sy._lib.EnvConfig(64, 200, 4, 20, 250, 1, 208, 5, 0, 0, 1, 0, 0)), C.byref(h2)) == 0
+    assert lib.sy_env_set_policy(h2, C.byref(w), 64) == -2
+    lib.sy_env_destroy(h2)
+
+
+def test_bench_starts_its_own_ranks_without_touching_the_gpu():
+    """`python bench.py --gpus N` without a launcher: the parent starts N children with the environment
+    torch.distributed.run would give them, relays rank 0's line and returns the worst exit code — and it does so before
+    importing torch or touching the GPU (the parent of GPU work must never have initialised the GPU itself)."""
+    import bench
+
+    started = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, stderr=None):
+            self.cmd, self.env, self.rank = cmd, env, int(env["RANK"])
+            self.returncode = None
+            self.terminated = False
+            started.append(self)
+
+        def communicate(self, timeout=None):
+            self.returncode = 0
+            return (b'{"n_gpus": 3}\n', None)
+
+        def wait(self, timeout=None):
+            self.returncode = 3 if self.rank == 2 else 0
+            return self.returncode
+
+        def terminate(self):
+            self.terminated = True
+
+        def kill(self):
+            self.terminated = True
+
+    rc = bench.spawn_ranks(3, ["--gpus", "3", "--steps", "2"], popen=FakeProc)
+    assert rc == 3                                                  # the worst child
+    assert [p.rank for p in started] == [0, 1, 2]
+    ports = {p.env["MASTER_PORT"] for p in started}
+    assert len(ports) == 1 and 1024 < int(ports.pop()) < 65536
+    for p in started:
+        assert p.env["WORLD_SIZE"] == "3" and p.env["LOCAL_RANK"] == p.env["RANK"] and p.env["MASTER_ADDR"] == "127.0.0.1"
+        assert p.env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+        assert p.cmd[0] == sys.executable and p.cmd[1].endswith("bench.py") and p.cmd[2:] == ["--gpus", "3", "--steps", "2"]
+    # the real thing, as a subprocess, on a machine without a GPU: both ranks fail at once (no device), the parent must
+    # report that with a non-zero exit code and must not have imported torch itself
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks would really run")
+    code = ("import sys, runpy; sys.argv = ['bench.py', '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-cpu']\n"
+            "try:\n    runpy.run_path(%r, run_name='__main__')\nexcept SystemExit as e:\n"
+            "    print('RC', e.code, 'TORCH', 'torch' in sys.modules)\n" % os.path.join(ROOT, "bench.py"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "TORCH False" in out.stdout and "RC 0" not in out.stdout, (out.stdout, out.stderr[-500:])

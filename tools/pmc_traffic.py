@@ -35,7 +35,11 @@ def main():
     assert fetch and write, 'no rollout_kernel dispatches found'
     f = sum(fetch) / len(fetch) * 1024.0
     w = sum(write) / len(write) * 1024.0
+    import os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+    from student_mechanism_design_amd import _lib
     rec = {
+        'build_id': _lib.build_id(),      # digest of the sources of the library the counters were collected from
         'config': {'nodes': 200, 'police': 4, 'envs': 4096, 'fused': fused},
         'kernel': kern, 'dispatches': len(fetch),
         'fetch_size_bytes_raw': f, 'write_size_bytes': w,

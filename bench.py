@@ -159,7 +159,7 @@ def cpu_baseline(args, boards, weights, env_graph, A):
 def verify_last_launch(args, boards, weights, env, snap, out, T):
     """Outside the timed region: the oracle restarts from the state snapshot taken just before the LAST timed launch
     and must reproduce that launch's recorded trajectory (bit-exact; belief within 1e-5) and the live state."""
-    orc = make_oracle(args, boards, weights, env.env_graph_host, usable_cores(), env_id_offset=int(env._env_id_offset))
+    orc = make_oracle(args, boards, weights, env.env_graph_host, usable_cores(), env_id_offset=env.env_id_offset)
     orc.reset(seed=env.stream_key)
     N = env.N
     orc.pos[:] = snap["pos"].cpu().numpy()
@@ -246,7 +246,6 @@ def main():
     env = sy.BatchedScotlandYardEnv(B, boards, P, args.money, weights, seed=args.seed, reveal_interval=args.reveal,
                                     env_id_offset=rank * B, waves_per_block=args.wpb, device=device,
                                     with_belief=not args.no_belief)
-    env._env_id_offset = rank * B
     out = None if args.no_record else env.alloc_rollout(T, record_mask=not args.no_mask_record)
     full = not (args.no_record or args.no_belief or args.no_mask_record)
     do_verify = full and not args.no_verify and rank == 0

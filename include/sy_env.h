@@ -225,7 +225,7 @@ int sy_masked_categorical_sample(const float *probs, int64_t probs_row_stride, c
  * masked sampling as in sy_masked_categorical_sample (an empty mask gives action -1), and the central critic on
  * [mrx] + [police] * P.  pos int32 [B][A], mask uint8 [B][A][mask_row_stride]; outputs action int32 [B][A],
  * log_prob float [B][A], value float [B] (NULL = skip the critic), probs float [B][A][N] (NULL = not wanted: the
- * actor's softmax before masking).  hidden <= 64. */
+ * actor's softmax before masking).  hidden <= 128 (the reference's default, src/configs/agent/default.yaml:2). */
 int sy_mappo_policy_act(const int32_t *pos, const uint8_t *mask, int64_t mask_row_stride, const sy_mappo_weights *w,
                         int32_t num_envs, int32_t num_police, int32_t num_nodes, int32_t hidden, uint64_t seed, uint64_t offset,
                         const uint64_t *offset_dev, int32_t *action, float *log_prob, float *value, float *probs, void *stream);

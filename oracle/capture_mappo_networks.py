@@ -5,7 +5,9 @@ Instantiates the UNMODIFIED `AgentPolicy` / `CentralCritic` (/root/reference/src
 imported by file path), seeds their weights, evaluates them on the observations the reference trainer
 builds (one-hot MrX node for MrX's actor, multi-hot police nodes for the police actors, their
 concatenation [mrx] + [police] * P for the critic: mappo_trainer.py:173,197) and writes weights, inputs
-and outputs to tests/golden/mappo_networks_reference.npz.
+and outputs to tests/golden/mappo_networks_reference.npz (N=14, P=3, hidden 8) and
+tests/golden/mappo_networks_reference_h128.npz (N=24, P=4, hidden 128 — the reference's default hidden size,
+src/configs/agent/default.yaml:2).
 
     python oracle/capture_mappo_networks.py
 """
@@ -19,12 +21,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.environ.get("SY_REFERENCE", "/root/reference")
 
 
-def main():
-    spec = importlib.util.spec_from_file_location("ref_mappo_agent", os.path.join(REF, "src", "agent", "mappo_agent.py"))
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
-    torch.manual_seed(77)
-    N, P, H, B = 14, 3, 8, 9
+def capture(mod, seed, N, P, H, B, fname):
+    torch.manual_seed(seed)
     A = P + 1
     actors = [mod.AgentPolicy(N, N, H) for _ in range(A)]
     critic = mod.CentralCritic(N * A, H)
@@ -41,9 +39,17 @@ def main():
             out[f"actor{k}.{name}"] = t.numpy()
     for name, t in critic.state_dict().items():
         out[f"critic.{name}"] = t.numpy()
-    path = os.path.join(HERE, "..", "tests", "golden", "mappo_networks_reference.npz")
+    path = os.path.join(HERE, "..", "tests", "golden", fname)
     np.savez_compressed(path, **out)
     print("wrote", os.path.abspath(path), sorted(k for k in out if "." in k)[:6], "...")
+
+
+def main():
+    spec = importlib.util.spec_from_file_location("ref_mappo_agent", os.path.join(REF, "src", "agent", "mappo_agent.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    capture(mod, 77, 14, 3, 8, 9, "mappo_networks_reference.npz")
+    capture(mod, 78, 24, 4, 128, 12, "mappo_networks_reference_h128.npz")
 
 
 if __name__ == "__main__":

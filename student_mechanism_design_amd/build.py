@@ -18,7 +18,7 @@ LIB = os.path.join(HERE, "libsy_env.so")
 FAULT_LIB = os.path.join(HERE, "libsy_env_fault.so")
 OBJ_ROOT = os.path.join(CSRC, "_obj")
 # translation units, the slowest first (the scheduler starts them in this order)
-SOURCES = ["sy_rollout3_p.hip", "sy_rollout2_c.hip", "sy_rollout1_b.hip", "sy_rollout2_a.hip", "sy_rollout1_a.hip",
+SOURCES = ["sy_rollout3_p.hip", "sy_rollout3_q.hip", "sy_rollout2_c.hip", "sy_rollout1_b.hip", "sy_rollout2_a.hip", "sy_rollout1_a.hip",
            "sy_rollout3_a.hip", "sy_rollout3_b.hip", "sy_rollout3_c.hip", "sy_rollout3_d.hip", "sy_rollout2_b.hip",
            "sy_policy.hip", "sy_aux.hip", "sy_step.hip", "sy_gnn.hip", "sy_returns.hip", "sy_dispatch.hip", "sy_capi.hip"]
 HEADERS = {

@@ -185,7 +185,9 @@ int sy_env_set_policy(sy_env* env, const sy_mappo_weights* w, int32_t hidden) {
     // the limits are those of the instance that will run (sy_dispatch.hip::plan_rollout — the launcher reads the same plan)
     const sy::RolloutPlan pl = sy::plan_rollout(env->p, true, env->wpb, env->lds, hidden);
     const int hmax = pl.family == 3 ? 128 : 64;
-    if (!pl.pol) return fail(SY_ERR_INVALID, "sy_env_set_policy: no policy instance for this configuration%s");
+    if (!pl.pol)
+        return fail(SY_ERR_INVALID, "sy_env_set_policy: no policy instance for this configuration (boards of more than 256 nodes, or "
+                    "max_timestep >= 2^20 - 2, need agents that fit one scan pass)%s");
     if (hidden > hmax)
         return fail(SY_ERR_INVALID, "sy_env_set_policy: hidden must be at most %s%lld for this configuration (128 on the pipeline kernel: "
                     "boards of up to 256 nodes, max_timestep < 2^20 - 2; 64 otherwise)", "", hmax);
@@ -296,7 +298,6 @@ int sy_env_rollout(sy_env* env, int32_t T, const sy_rollout_buffers* out, void* 
     if (o.mask && (reinterpret_cast<uintptr_t>(o.mask) & 15)) return fail(SY_ERR_INVALID, "rollout mask must be 16-byte aligned%s");
     if (env->p.pw2) {       // learned policy in the kernel: recorded rollouts on single-pass boards
         if (!o.record) return fail(SY_ERR_INVALID, "sy_env_rollout: a policy rollout needs a record%s");
-        if (env->p.A > 64 / env->p.scan_w) return fail(SY_ERR_INVALID, "sy_env_rollout: the in-kernel policy needs boards whose agents fit one scan pass%s");
         // the instance is chosen per launch: a board pool bound after sy_env_set_policy may have moved it
         const sy::RolloutPlan pl = sy::plan_rollout(env->p, true, env->wpb, env->lds);
         if (!pl.pol || pl.pslice != env->p.pslice || env->p.pH > (pl.family == 3 ? 128 : 64) || pl.lds > kMaxLds)
@@ -353,7 +354,7 @@ int sy_mappo_policy_act(const int32_t* pos, const uint8_t* mask, int64_t mask_ro
     if (value && (!w->c1t || !w->cb1 || !w->c2 || !w->cb2)) return fail(SY_ERR_INVALID, "sy_mappo_policy_act: null critic weights%s");
     if (num_police < 1 || num_police > SY_MAX_AGENTS - 1 || num_nodes < 1 || num_nodes > SY_MAX_NODES || mask_row_stride < num_nodes)
         return fail(SY_ERR_INVALID, "sy_mappo_policy_act: bad sizes%s");
-    if (hidden < 1 || hidden > 64) return fail(SY_ERR_INVALID, "sy_mappo_policy_act: hidden size must be in [1, 64]%s");
+    if (hidden < 1 || hidden > 128) return fail(SY_ERR_INVALID, "sy_mappo_policy_act: hidden size must be in [1, 128]%s");
     if (num_envs < 0) return fail(SY_ERR_INVALID, "sy_mappo_policy_act: bad num_envs%s");
     if (num_envs == 0) return SY_OK;
     hipError_t e = sy::launch_mappo_policy(pos, mask, mask_row_stride, w->w1t, w->b1, w->w2t, w->b2, w->c1t, w->cb1, w->c2, w->cb2,

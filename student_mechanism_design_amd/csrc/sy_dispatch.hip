@@ -45,12 +45,35 @@ RolloutPlan plan_rollout(const EngineParams& p, bool record, int wpb, size_t lds
     const int threads3 = 64 * wpb;
     const int threads12 = paired ? 64 * (wpb / 2 + (has_belief ? wpb / 2 : 0))
                                  : 64 * (wpb + (has_belief ? (wpb + 1) / 2 : 0));   // move waves + belief waves
-    if (pol && pol_pipeline && p.A <= per_pass) {          // learned policy in the move wave: single-pass boards
+    // learned policy in the move wave: the half-wave scan (no passes: any row width) for the police counts with a
+    // compile-time instance — the smallest column count that covers the pool's widest row —, the single-pass paired
+    // scan for the other counts
+    int pol_hs = 0;
+    if (pol && pol_pipeline) {
+        const int P = p.P;
+        const int need = hs_need;
+        if (pl.nr == 4) {
+            if (P == 2 && need <= 2) pol_hs = 2;
+            else if (P == 4 && need <= 3) pol_hs = need <= 2 ? 2 : 3;
+            else if (P == 5 && need <= 4) pol_hs = need <= 2 ? 2 : 4;
+            else if (P == 6 && need <= 4) pol_hs = need <= 3 ? 3 : 4;
+            else if (P == 7 && need <= 4) pol_hs = 4;
+        } else {
+            if (P == 2 && need <= 2) pol_hs = 2;
+            else if (P == 4 && need <= 3) pol_hs = 3;
+            else if ((P == 5 || P == 6 || P == 7) && need <= 4) pol_hs = 4;
+        }
+    }
+    if (pol && pol_pipeline && pol_hs > 0) {
         pl.family = 3;
         pl.rec = true;
-        pl.pt = pl.pt == 4 ? 4 : 0;
-        pl.hs = (pl.pt == 4 && hs_cols > 0 && hs_cols <= 2) ? 2 : 0;   // 4 police: the half-wave scan, one logit stream per lane
-    } else if (pol && paired) {
+        pl.pt = p.P;
+        pl.hs = pol_hs;
+    } else if (pol && pol_pipeline && p.A <= per_pass) {
+        pl.family = 3;
+        pl.rec = true;
+        pl.pt = 0;
+    } else if (pol && paired && p.A <= per_pass) {        // round 1's kernel: single-pass boards, hidden <= 64
         pl.family = 2;
         pl.rec = true;
         pl.pt = pl.pt == 4 ? 4 : 0;
@@ -66,7 +89,8 @@ RolloutPlan plan_rollout(const EngineParams& p, bool record, int wpb, size_t lds
         }
     } else {
         pl.family = paired ? 2 : 1;
-        pl.pol = false;                                    // (odd block sizes have no policy instance: the ABI refuses them)
+        pl.pol = false;      // no policy instance (odd block sizes; boards of more than 256 nodes whose agents need two scan
+                             // passes): sy_env_set_policy / sy_env_rollout refuse these configurations
     }
     if (pl.pol) pl.pslice = rollout_policy_slice(pl.family, p.A, H);
     pl.threads = pl.family == 3 ? threads3 : threads12;
@@ -87,7 +111,7 @@ hipError_t launch_rollout(const EngineParams& p, int T, const sy_rollout_buffers
     const RolloutPlan pl = plan_rollout(p, out.record != nullptr, wpb, lds);
     bool ok = false;
     if (pl.family == 3) {
-        if (pl.pol) ok = launch_r3_p(pl, p, T, out, blocks, stream);
+        if (pl.pol) ok = pl.nr == 4 ? launch_r3_p(pl, p, T, out, blocks, stream) : launch_r3_q(pl, p, T, out, blocks, stream);
         else if (pl.nr == 4) ok = pl.rec ? launch_r3_a(pl, p, T, out, blocks, stream) : launch_r3_b(pl, p, T, out, blocks, stream);
         else ok = pl.nr == 1 ? launch_r3_c(pl, p, T, out, blocks, stream) : launch_r3_d(pl, p, T, out, blocks, stream);
     } else if (pl.family == 2) {

@@ -73,7 +73,7 @@ hipError_t launch_step(const EngineParams& p, const int32_t* actions, const sy_r
                        hipStream_t stream);
 // instance groups (one translation unit each); false = the planned instance is not in that unit
 #define SY_DECL_GROUP(name) bool name(const RolloutPlan& pl, const EngineParams& p, int T, const sy_rollout_buffers& out, int blocks, hipStream_t stream)
-SY_DECL_GROUP(launch_r3_a); SY_DECL_GROUP(launch_r3_b); SY_DECL_GROUP(launch_r3_c); SY_DECL_GROUP(launch_r3_d); SY_DECL_GROUP(launch_r3_p);
+SY_DECL_GROUP(launch_r3_a); SY_DECL_GROUP(launch_r3_b); SY_DECL_GROUP(launch_r3_c); SY_DECL_GROUP(launch_r3_d); SY_DECL_GROUP(launch_r3_p); SY_DECL_GROUP(launch_r3_q);
 SY_DECL_GROUP(launch_r2_a); SY_DECL_GROUP(launch_r2_b); SY_DECL_GROUP(launch_r2_c);
 SY_DECL_GROUP(launch_r1_a); SY_DECL_GROUP(launch_r1_b);
 #undef SY_DECL_GROUP

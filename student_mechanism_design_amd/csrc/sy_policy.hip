@@ -137,7 +137,7 @@ __global__ __launch_bounds__(1024) void mappo_policy_kernel(const int32_t* __res
                                                             float* __restrict__ probs_out) {
     // block = 16 waves = 16 envs of one agent (grid.y = agent; y == A: the critic's blocks)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int kHS = 65;                                      // hidden row stride (floats): conflict-free A-operand reads
+    constexpr int kHS = 129;                                     // hidden row stride (floats): conflict-free A-operand reads; H <= 128
     const int LS = NR * 64 + 1;                                  // logits row stride
     float* hs = reinterpret_cast<float*>(smem);                  // [16][kHS]   hidden activations of the block's 16 rows
     float* ls = hs + 16 * kHS;                                   // [16][LS]    their logits
@@ -150,27 +150,35 @@ __global__ __launch_bounds__(1024) void mappo_policy_kernel(const int32_t* __res
     if (a == A) {
         // ---- central critic: h = relu(cb1 + C1t[mrx] + sum_k sum_j C1t[N (1 + k) + police_j]), value = c2 . h + cb2
         if (!value || !live) return;
-        float h = lane < H ? w.cb1[lane] : 0.0f;
-        if (lane < H) {
-            h += w.c1t[(size_t)prow[0] * H + lane];
-            for (int k = 0; k < P; ++k)
-                for (int j = 0; j < P; ++j) h += w.c1t[((size_t)N * (1 + k) + prow[1 + j]) * H + lane];
+        float part = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {                           // hidden units lane, lane + 64 (H <= 128)
+            const int k = lane + 64 * u;
+            if (k < H) {
+                float h = w.cb1[k];
+                h += w.c1t[(size_t)prow[0] * H + k];
+                for (int kk = 0; kk < P; ++kk)
+                    for (int j = 0; j < P; ++j) h += w.c1t[((size_t)N * (1 + kk) + prow[1 + j]) * H + k];
+                h = h > 0.0f ? h : 0.0f;
+                part += h * w.c2[k];
+            }
         }
-        h = h > 0.0f ? h : 0.0f;
-        const float v = wave_sum(lane < H ? h * w.c2[lane] : 0.0f) + w.cb2[0];
+        const float v = wave_sum(part) + w.cb2[0];
         if (lane == 0) value[b] = v;
         return;
     }
-    // ---- phase 1: actor a's first layer by row lookups (lane k holds hidden unit k of this wave's env)
-    {
-        float h = lane < H ? w.b1[(size_t)a * H + lane] : 0.0f;
-        if (lane < H && live) {
+    // ---- phase 1: actor a's first layer by row lookups (lane k holds hidden units k and k + 64 of this wave's env)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int k = lane + 64 * u;
+        float h = k < H ? w.b1[(size_t)a * H + k] : 0.0f;
+        if (k < H && live) {
             const float* w1a = w.w1t + (size_t)a * N * H;
-            if (a == 0) h += w1a[(size_t)prow[0] * H + lane];
+            if (a == 0) h += w1a[(size_t)prow[0] * H + k];
             else
-                for (int j = 0; j < P; ++j) h += w1a[(size_t)prow[1 + j] * H + lane];
+                for (int j = 0; j < P; ++j) h += w1a[(size_t)prow[1 + j] * H + k];
         }
-        hs[wid * kHS + lane] = (lane < H && h > 0.0f) ? h : 0.0f;
+        hs[wid * kHS + k] = (k < H && h > 0.0f) ? h : 0.0f;
     }
     __syncthreads();
     // ---- phase 2: logits[16 envs][N] = hs[16][H] x W2t[H][N] + b2 on the matrix cores (f32 in, f32 accumulate):
@@ -271,7 +279,7 @@ hipError_t launch_mappo_policy(const int32_t* pos, const uint8_t* mask, long lon
     const uint32_t lo = (uint32_t)seed, hi = (uint32_t)(seed >> 32);
     const int nr = (N + 63) / 64;
     const int nrp = nr <= 1 ? 1 : (nr <= 2 ? 2 : (nr <= 4 ? 4 : (nr <= 8 ? 8 : 16)));
-    const size_t lds = (size_t)(16 * 65 + 16 * (nrp * 64 + 1)) * sizeof(float);   // hidden rows + logits rows of 16 envs
+    const size_t lds = (size_t)(16 * 129 + 16 * (nrp * 64 + 1)) * sizeof(float);   // hidden rows + logits rows of 16 envs
 #define SY_LAUNCH_MP(NR_) hipLaunchKernelGGL((mappo_policy_kernel<NR_>), grid, dim3(wpb * 64), lds, stream, pos, mask,        \
                                              mask_row_stride, w, B, A, N, H, lo, hi, offset, offset_dev, action, log_prob,   \
                                              value, probs_out)

@@ -349,7 +349,7 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
     }
     wave_lds_fence();
     // up to 5 agents, random policy (police count fixed at compile time): one episode per half wave in the scan
-    constexpr bool HALF = HS > 0 && PT >= 1 && PT <= 6;
+    constexpr bool HALF = HS > 0 && PT >= 1 && PT <= 7;
     constexpr int GWH = HALF ? half_scan_gw(PT) : kD;
     HalfScan<GWH, (HALF ? HS : 1)> hs;
     if (HALF) hs.init(L, E, E1, lane, A, NS);

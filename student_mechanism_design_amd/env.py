@@ -142,6 +142,7 @@ class BatchedScotlandYardEnv:
         self.agent_money, self.max_timestep = int(agent_money), int(max_timestep)
         self.possible_agents = ["MrX"] + [f"Police{k}" for k in range(self.P)]
         self.seed = int(seed)
+        self.env_id_offset = int(env_id_offset)   # global index of env 0 (rank * B): names the Philox sub-streams
         self.reset_epoch = 0          # seedless full resets since the last explicit seed (see `reset`)
         cfg = _lib.EnvConfig(self.B, self.N, self.P, self.agent_money, self.max_timestep, self.G, self.NS,
                              int(reveal_interval), int(bool(police_evidence)), int(bool(belief_init_onehot)),

@@ -123,8 +123,7 @@ class DeviceMappoPolicy:
             raise _lib.EngineError("DeviceMappoPolicy needs the module on a GPU; there is no CPU fallback")
         self.H = net.actors[0][0].out_features
         if self.H > 128 or self.H % 4:
-            raise ValueError("the fused kernels support hidden sizes that are multiples of 4, up to 128 "
-                             "(sy_mappo_policy_act: up to 64)")
+            raise ValueError("the fused kernels support hidden sizes that are multiples of 4, up to 128")
         self.seed = int(seed) & (2**64 - 1)
         self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
         self._out = None
@@ -175,8 +174,6 @@ class DeviceMappoPolicy:
         """Collector callback: (actions int32 [B, A], log_prob [B, A], value [B]); with want_probs a 4th item,
         the actors' softmax [B, A, N].  The first three are persistent buffers, overwritten by the next call."""
         import ctypes as C
-        if self.H > 64:
-            raise ValueError("sy_mappo_policy_act supports hidden sizes up to 64 (the in-kernel policy, env.set_policy, up to 128)")
         pos, mask = obs["agent_position"], obs["action_mask"]
         B, A = pos.shape
         N = self.net.N

@@ -394,6 +394,41 @@ def test_step_record_fills_the_row_the_collector_used_to_copy(sy):
     b.close()
 
 
+def _load_reference_networks(pol, fixture, device):
+    """A MappoPolicy carrying the weights of the unmodified reference networks (tests/golden/<fixture>)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
+    n, pp, hh = int(g["N"]), int(g["P"]), int(g["H"])
+    net = pol.MappoPolicy(n, pp, hidden_size=hh).to(device)
+    with torch.no_grad():
+        for k in range(pp + 1):
+            for li, nm in ((0, "0"), (2, "2")):
+                net.actors[k][li].weight.copy_(torch.from_numpy(g[f"actor{k}.actor.{nm}.weight"]))
+                net.actors[k][li].bias.copy_(torch.from_numpy(g[f"actor{k}.actor.{nm}.bias"]))
+        for li, nm in ((0, "0"), (2, "2")):
+            net.critic[li].weight.copy_(torch.from_numpy(g[f"critic.critic.{nm}.weight"]))
+            net.critic[li].bias.copy_(torch.from_numpy(g[f"critic.critic.{nm}.bias"]))
+    return g, net
+
+
+def _policy_weights(net):
+    """torch Linear layouts of the actors as float64 numpy (what oracle/policy_oracle.py takes)."""
+    st = lambda f: np.stack([_np(f(a)).astype(np.float64) for a in net.actors])
+    return {"W1": st(lambda a: a[0].weight), "b1": st(lambda a: a[0].bias), "W2": st(lambda a: a[2].weight), "b2": st(lambda a: a[2].bias)}
+
+
+def _check_policy_rollout(env, rec, net, step_count0, T):
+    """The in-kernel policy's recorded actions / log-probabilities against the float64 restatement of the draw
+    (oracle/policy_oracle.py): the action is the restatement's arg-max wherever its top-2 key margin exceeds 1e-4,
+    the log-probability of the recorded action agrees to 1e-4."""
+    from oracle import policy_oracle as po
+    ell = env.pool.ell
+    d = po.policy_draws(_np(rec["pos"][:T]), _np(rec["budget"][:T]), step_count0.astype(np.uint32),
+                        env.env_id_offset + np.arange(env.B), lambda b: ell[env.env_graph_host[b]],
+                        _policy_weights(net), env.stream_key)
+    return po.check_recorded_policy_rollout(_np(rec["action"][:T]), _np(rec["log_prob"][:T]), d), d
+
+
 def test_fused_mappo_policy_kernel_matches_the_torch_module_and_the_reference(sy):
     """sy_mappo_policy_act (actor MLPs + masked sampling + critic in one launch) against MappoPolicy in torch
     on live env observations, and against the outputs of the unmodified reference networks
@@ -433,23 +468,22 @@ def test_fused_mappo_policy_kernel_matches_the_torch_module_and_the_reference(sy
     fused.refresh()
     _, _, _, p2 = fused.act(obs, want_probs=True)
     assert float(p2[:, 0, 3].min()) > 0.99
-    # the unmodified reference networks (goldens): same probabilities and values from their weights
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mappo_networks_reference.npz"))
-    n, pp, hh = int(g["N"]), int(g["P"]), int(g["H"])
-    small = pol.MappoPolicy(n, pp, hidden_size=hh).to(env.device)
+    # the unmodified reference networks (goldens): same probabilities and values from their weights — hidden 8, and the
+    # reference's default hidden size 128 (src/configs/agent/default.yaml:2)
+    for fixture in ("mappo_networks_reference.npz", "mappo_networks_reference_h128.npz"):
+        g, small = _load_reference_networks(pol, fixture, env.device)
+        pp = int(g["P"])
+        pos = torch.from_numpy(g["pos"]).to(env.device).int().contiguous()
+        full_mask = torch.ones((pos.shape[0], pp + 1, 32), dtype=torch.uint8, device=env.device)
+        _, _, v3, p3 = pol.DeviceMappoPolicy(small, seed=1).act({"agent_position": pos, "action_mask": full_mask}, want_probs=True)
+        np.testing.assert_allclose(_np(p3), g["probs"], rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(_np(v3), g["value"], rtol=1e-4, atol=1e-5)
+    # hidden 128 on live observations of the 200-node env, against the torch module
+    net128 = pol.MappoPolicy(N, P, hidden_size=128).to(env.device)
+    a128, lp128, v128, p128 = pol.DeviceMappoPolicy(net128, seed=2).act(obs, want_probs=True)
     with torch.no_grad():
-        for k in range(pp + 1):
-            for li, nm in ((0, "0"), (2, "2")):
-                small.actors[k][li].weight.copy_(torch.from_numpy(g[f"actor{k}.actor.{nm}.weight"]))
-                small.actors[k][li].bias.copy_(torch.from_numpy(g[f"actor{k}.actor.{nm}.bias"]))
-        for li, nm in ((0, "0"), (2, "2")):
-            small.critic[li].weight.copy_(torch.from_numpy(g[f"critic.critic.{nm}.weight"]))
-            small.critic[li].bias.copy_(torch.from_numpy(g[f"critic.critic.{nm}.bias"]))
-    pos = torch.from_numpy(g["pos"]).to(env.device).int().contiguous()
-    full_mask = torch.ones((pos.shape[0], pp + 1, 16), dtype=torch.uint8, device=env.device)
-    _, _, v3, p3 = pol.DeviceMappoPolicy(small, seed=1).act({"agent_position": pos, "action_mask": full_mask}, want_probs=True)
-    np.testing.assert_allclose(_np(p3), g["probs"], rtol=2e-4, atol=1e-7)
-    np.testing.assert_allclose(_np(v3), g["value"], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(_np(p128), _np(net128.probs(obs)), rtol=2e-4, atol=1e-7)
+        np.testing.assert_allclose(_np(v128), _np(net128.value(obs)), rtol=1e-4, atol=1e-5)
     env.close()
 
 
@@ -472,6 +506,8 @@ def test_fused_rollout_with_the_mappo_policy_in_the_kernel(sy):
             a[2].bias.normal_(0.0, 2.5)
     fused = pol.DeviceMappoPolicy(net, seed=5)
     env.set_policy(fused)
+    assert env.rollout_kernel_name() == "sy::rollout3_kernel<4,true,4,true,2>"
+    sc0 = _np(env.step_count).copy()
     rec = env.rollout(T)
     torch.cuda.synchronize()
     act, mask = rec["action"].long(), rec["mask"][..., :N].bool()
@@ -486,22 +522,22 @@ def test_fused_rollout_with_the_mappo_policy_in_the_kernel(sy):
         twin.step(rec["action"][s].contiguous())
         np.testing.assert_array_equal(_np(twin.reward), _np(rec["reward"][s]))
     np.testing.assert_array_equal(_np(twin.pos), _np(env.pos))
-    # log-probabilities: masked, renormalised softmax of the module on the recorded observations
+    # the draw itself, deterministically: the recorded action is the arg-max of logit + Gumbel(Philox word, ELL column)
+    # of the float64 restatement wherever its top-2 margin exceeds 1e-4; log-probabilities agree to 1e-4
+    stats, d = _check_policy_rollout(env, rec, net, sc0, T)
+    assert stats["decided"] > 0.99 * (stats["agents"] - int(_np(empty).sum())), stats
+    # and the restatement's log-probabilities are those of the torch module's masked, renormalised softmax
     pos = rec["pos"].reshape(T * B, P + 1)
     with torch.no_grad():
         probs = net.probs_fast({"MrX_pos": pos[:, 0], "Polices_pos": pos[:, 1:]}).reshape(T, B, P + 1, N)
     pm = probs * mask.float()
     norm = pm / pm.sum(-1, keepdim=True).clamp_min(1e-30)
     want = torch.log(torch.gather(norm, -1, act.clamp_min(0).unsqueeze(-1)).squeeze(-1))
-    got = rec["log_prob"]
     ok = ~empty
-    np.testing.assert_allclose(_np(got)[_np(ok)], _np(want)[_np(ok)], rtol=0, atol=2e-3)
-    assert bool((got[empty] == 0).all())
-    # the draws follow the distribution: mean probability of the chosen action vs its expectation sum_n p_n^2
+    np.testing.assert_allclose(_np(rec["log_prob"])[_np(ok)], _np(want)[_np(ok)], rtol=0, atol=3e-4)
+    assert bool((rec["log_prob"][empty] == 0).all())
+    # it is not the uniform policy: the chosen actions are far likelier under the network than uniform picks
     chosen = torch.gather(norm, -1, act.clamp_min(0).unsqueeze(-1)).squeeze(-1)[ok]
-    expect = (norm ** 2).sum(-1)[ok]
-    assert abs(float(chosen.mean()) - float(expect.mean())) < 0.02, (float(chosen.mean()), float(expect.mean()))
-    # and it is not the uniform policy: the chosen actions are far likelier under the network than uniform picks
     uniform_pick = (1.0 / mask.float().sum(-1).clamp_min(1))[ok]
     assert float(chosen.mean()) > float(uniform_pick.mean()) + 0.1
     # refresh(): new weights reach the kernel through the same packed buffers
@@ -522,43 +558,76 @@ def test_fused_rollout_with_the_mappo_policy_in_the_kernel(sy):
     twin.close()
 
 
-@pytest.mark.parametrize("N,P,H,B", [(60, 2, 32, 50), (90, 6, 16, 31), (24, 3, 64, 9)])
-def test_in_kernel_policy_other_shapes(sy, N, P, H, B):
-    """sy_env_set_policy on the generic-police-count instance, smaller hidden sizes and odd batch sizes:
-    legal actions, log-probabilities of the masked softmax, a trajectory that replays through step()."""
+@pytest.mark.parametrize("N,P,H,B,E", [(60, 2, 32, 50, None), (90, 6, 16, 31, None), (24, 3, 64, 9, None), (140, 5, 64, 40, None),
+                                       (200, 6, 128, 24, 400), (150, 7, 32, 18, None), (40, 6, 64, 16, 75), (100, 4, 128, 33, None)])
+def test_in_kernel_policy_other_shapes(sy, N, P, H, B, E):
+    """sy_env_set_policy on every police count (half-wave instances for 2, 4, 5, 6, 7 police — no scan-pass limit: boards
+    whose rows need two passes of the paired scan included —, the generic paired-scan instance for the others), hidden
+    sizes up to 128 and odd batch sizes: legal actions, a trajectory that replays through step(), and the draw held to the
+    float64 restatement (oracle/policy_oracle.py)."""
     from student_mechanism_design_amd import policies as pol
-    boards = sy.sample_board_pool(2, N, int(1.7 * N), seed=N)
+    boards = sy.sample_board_pool(2, N, E or int(1.7 * N), seed=N)
     w = np.linspace(0.1, 0.9, 11)
-    env = sy.BatchedScotlandYardEnv(B, boards, P, 7, w, seed=N + P, reveal_interval=3)
-    if env.A > 64 // max(8, env.max_degree if env.max_degree <= 12 else 16):
-        pytest.skip("board needs two scan passes: the in-kernel policy does not apply")
-    twin = sy.BatchedScotlandYardEnv(B, boards, P, 7, w, seed=N + P, reveal_interval=3)
+    wpb = 12 if (H == 128 and P >= 6) else 0          # hidden 128 with 7 agents: 12 episodes per block fit the LDS
+    env = sy.BatchedScotlandYardEnv(B, boards, P, 7, w, seed=N + P, reveal_interval=3, waves_per_block=wpb)
+    twin = sy.BatchedScotlandYardEnv(B, boards, P, 7, w, seed=N + P, reveal_interval=3, waves_per_block=wpb)
     torch.manual_seed(N)
     net = pol.MappoPolicy(N, P, hidden_size=H).to(env.device)
     with torch.no_grad():
         for a in net.actors:
             a[2].bias.normal_(0.0, 2.0)
     env.set_policy(pol.DeviceMappoPolicy(net, seed=1))
+    name = env.rollout_kernel_name()
+    assert name.startswith("sy::rollout3_kernel<") and ",true," in name, name
+    if P in (2, 4, 5, 6, 7):
+        assert not name.endswith(",0>"), name            # a half-wave instance
     T = 30
+    sc0 = _np(env.step_count).copy()
     rec = env.rollout(T)
     torch.cuda.synchronize()
+    env.check_status()
     act, mask = rec["action"].long(), rec["mask"][..., :N].bool()
     empty = mask.sum(-1) == 0
     assert bool((act[empty] == -1).all()) and bool((act[~empty] >= 0).all())
     assert bool(torch.gather(mask, -1, act.clamp_min(0).unsqueeze(-1)).squeeze(-1)[~empty].all())
     for s in range(T):
         np.testing.assert_array_equal(_np(twin.pos), _np(rec["pos"][s]))
+        np.testing.assert_array_equal(_np(twin._mask), _np(rec["mask"][s]))
         twin.step(rec["action"][s].contiguous())
         np.testing.assert_array_equal(_np(twin.reward), _np(rec["reward"][s]))
-    pos = rec["pos"].reshape(T * B, P + 1)
-    with torch.no_grad():
-        probs = net.probs({"MrX_pos": pos[:, 0], "Polices_pos": pos[:, 1:]}).reshape(T, B, P + 1, N)
-    pm = probs * mask.float()
-    norm = pm / pm.sum(-1, keepdim=True).clamp_min(1e-30)
-    want = torch.log(torch.gather(norm, -1, act.clamp_min(0).unsqueeze(-1)).squeeze(-1))
-    np.testing.assert_allclose(_np(rec["log_prob"])[_np(~empty)], _np(want)[_np(~empty)], rtol=0, atol=2e-3)
+    stats, _ = _check_policy_rollout(env, rec, net, sc0, T)
+    assert stats["decided"] > 0.98 * (stats["agents"] - int(_np(empty).sum())), stats
     env.close()
     twin.close()
+
+
+def test_in_kernel_policy_at_full_size_on_the_configs3_shard(sy):
+    """BASELINE configs[3] is a LEARNED policy on 6 police: the in-kernel MAPPO actors on the bench's own board pool
+    (N=200, E=400: widest row 10 — two passes of the paired scan, one half-wave pass of 3 columns per lane), 4096 envs
+    with the env ids of rank 3, and configs[2]'s shape (4 police) beside it; every draw held to the float64 restatement."""
+    from student_mechanism_design_amd import policies as pol
+    for P, offset, T in ((6, 3 * 4096, 24), (4, 0, 24)):
+        N, B = 200, 4096
+        boards = sy.sample_board_pool(8, N, 400, seed=0)
+        env = sy.BatchedScotlandYardEnv(B, boards, P, 20, np.full(11, 0.5), seed=99, reveal_interval=5, env_id_offset=offset)
+        torch.manual_seed(P)
+        net = pol.MappoPolicy(N, P, hidden_size=64).to(env.device)
+        with torch.no_grad():
+            for a in net.actors:
+                a[2].weight.mul_(4.0)
+                a[2].bias.normal_(0.0, 2.0)
+        env.set_policy(pol.DeviceMappoPolicy(net, seed=2))
+        assert env.max_degree >= 9 or P == 4
+        assert env.rollout_kernel_name() == ("sy::rollout3_kernel<4,true,6,true,3>" if P == 6 else "sy::rollout3_kernel<4,true,4,true,2>")
+        env.rollout(3, record=True)                      # move off the reset state (step counters no longer 0)
+        sc0 = _np(env.step_count).copy()
+        rec = env.rollout(T)
+        torch.cuda.synchronize()
+        env.check_status()
+        stats, d = _check_policy_rollout(env, rec, net, sc0, T)
+        assert stats["decided"] > 0.99 * (d["count"] > 0).sum(), stats
+        assert stats["max_logp_err"] <= 1e-4
+        env.close()
 
 
 # ----------------------------------------------------------------------------------------------
@@ -847,8 +916,11 @@ def test_in_kernel_policy_underflow_rule_and_hidden_128(sy):
         fused = pol.DeviceMappoPolicy(net, seed=9)
         assert float(fused._packed["logit_bound"][0]) >= 55.0          # the cheap bound cannot rule the underflow out
         env.set_policy(fused)
+        sc0 = _np(env.step_count).copy()
         rec = env.rollout(T)
         env.check_status()
+        stats, d = _check_policy_rollout(env, rec, net, sc0, T)     # every draw against the float64 restatement, both branches
+        assert stats["fallbacks"] > 100 and stats["decided"] > 0.98 * int((d["count"] > 0).sum()), stats
         act, mask = rec["action"].long(), rec["mask"][..., :N].bool()
         empty = mask.sum(-1) == 0
         assert bool((act[empty] == -1).all()) and bool((act[~empty] >= 0).all())
@@ -859,7 +931,7 @@ def test_in_kernel_policy_underflow_rule_and_hidden_128(sy):
         want, fell_back = _reference_rule_log_prob(probs, mask, act)
         got = rec["log_prob"]
         ok = ~empty
-        np.testing.assert_allclose(_np(got)[_np(ok)], _np(want)[_np(ok)], rtol=0, atol=2e-3)
+        np.testing.assert_allclose(_np(got)[_np(ok)], _np(want)[_np(ok)], rtol=0, atol=3e-4)
         fb0 = fell_back[..., 0] & ok[..., 0]
         assert int(fb0.sum()) > 100 and int((~fell_back[..., 0] & ok[..., 0]).sum()) > 0      # both branches of the rule ran
         cnt0 = mask[..., 0, :].sum(-1).float()

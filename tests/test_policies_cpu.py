@@ -1,5 +1,6 @@
 """CPU tests of the torch policies (device-agnostic code; the env side is covered by the GPU tests)."""
 import numpy as np
+import pytest
 import torch
 
 import student_mechanism_design_amd as sy
@@ -37,12 +38,13 @@ def test_mappo_policy_shapes_and_masking():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
 
 
-def test_mappo_policy_matches_the_reference_networks():
-    """tests/golden/mappo_networks_reference.npz: weights, inputs and outputs of the UNMODIFIED AgentPolicy /
+@pytest.mark.parametrize("fixture", ["mappo_networks_reference.npz", "mappo_networks_reference_h128.npz"])
+def test_mappo_policy_matches_the_reference_networks(fixture):
+    """tests/golden/mappo_networks_reference*.npz (hidden 8, and the reference's default hidden 128): weights, inputs and outputs of the UNMODIFIED AgentPolicy /
     CentralCritic (oracle/capture_mappo_networks.py).  MappoPolicy loaded with those weights must reproduce the
     reference's action probabilities and values, through both the reference-shaped and the one-hot-free path."""
     import os
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mappo_networks_reference.npz"))
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
     N, P, H = int(g["N"]), int(g["P"]), int(g["H"])
     net = pol.MappoPolicy(N, P, hidden_size=H)
     with torch.no_grad():
@@ -125,3 +127,66 @@ def test_device_policy_and_sampler_refuse_to_run_without_a_gpu():
         pol.DeviceMappoPolicy(net)
     with pytest.raises(sy.EngineError):
         col.DeviceMaskedSampler(torch.device("cpu"))
+
+
+def test_policy_oracle_philox_and_softmax_are_pinned():
+    """oracle/policy_oracle.py (the restatement the GPU tests hold the in-kernel policy to) against independent
+    implementations: its numpy Philox4x32-7 against the C oracle's (which the env parity tests pin through the action
+    draws of the random policy), and its masked, renormalised log-probabilities against `masked_categorical_sample` on
+    `MappoPolicy.probs` — the torch restatement that the goldens of the unmodified reference pin."""
+    from oracle import oracle_lib as ol, policy_oracle as po
+    from student_mechanism_design_amd import collector as col
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        gid = int(rng.integers(0, 2**40))
+        ctr, idx = int(rng.integers(0, 2**32)), int(rng.integers(0, 8))
+        k0, k1 = int(rng.integers(0, 2**32)), int(rng.integers(0, 2**32))
+        want = ol.philox(gid & 0xFFFFFFFF, gid >> 32, ctr, (1 << 8) | idx, k0, k1)
+        got = po.philox4x32_7(np.array([gid], dtype=np.uint64), np.array([ctr]), 1, np.array([idx]), k0, k1)[0]
+        assert list(map(int, got)) == list(map(int, want))
+    N, P, H, B = 30, 3, 16, 40
+    import student_mechanism_design_amd as sy
+    board = sy.sample_board(N, 55, rng=np.random.default_rng(4))
+    ell = sy.pack_ell(board)
+    torch.manual_seed(0)
+    net = pol.MappoPolicy(N, P, hidden_size=H)
+    with torch.no_grad():
+        for a in net.actors:
+            a[2].bias.normal_(0.0, 2.0)
+    pos = np.stack([rng.permutation(N)[: P + 1] for _ in range(B)])[None]           # [1][B][A]
+    budget = np.concatenate([np.full((1, B, 1), 1000), rng.integers(0, 5, size=(1, B, P))], axis=2)
+    weights = {"W1": np.stack([a[0].weight.detach().numpy() for a in net.actors]), "b1": np.stack([a[0].bias.detach().numpy() for a in net.actors]),
+               "W2": np.stack([a[2].weight.detach().numpy() for a in net.actors]), "b2": np.stack([a[2].bias.detach().numpy() for a in net.actors])}
+    d = po.policy_draws(pos, budget, np.zeros(B, dtype=np.uint32), np.arange(B), lambda b: ell, weights, stream_key=77)
+    # the torch path: masks from the ELL, the module's softmax, select_action's normalisation
+    mask = np.zeros((B, P + 1, N), dtype=bool)
+    for b in range(B):
+        for a in range(P + 1):
+            row = ell[pos[0, b, a]]
+            ok = (row >> 16) <= budget[0, b, a]
+            mask[b, a, (row & 0xFFFF)[ok]] = True
+    assert (mask.sum(-1) == d["count"][0]).all()
+    with torch.no_grad():
+        probs = net.probs({"MrX_pos": torch.from_numpy(pos[0, :, 0]), "Polices_pos": torch.from_numpy(pos[0, :, 1:])})
+        _, _, p = col.masked_categorical_sample(probs.double(), torch.from_numpy(mask), generator=torch.Generator().manual_seed(1))
+    norm = (p / p.sum(-1, keepdim=True)).numpy()
+    for b in range(B):
+        for a in range(P + 1):
+            for k in range(16):
+                n = d["nodes"][0, b, a, k]
+                if n >= 0:
+                    assert abs(np.exp(d["logp_entries"][0, b, a, k]) - norm[b, a, n]) < 1e-6
+    # arg-max consistency and the checker's own bookkeeping
+    best = d["keys"][0].argmax(-1)
+    has = d["count"][0] > 0
+    assert (np.take_along_axis(d["nodes"][0], best[..., None], -1)[..., 0][has] == d["action"][0][has]).all()
+    stats = po.check_recorded_policy_rollout(d["action"], d["log_prob"], d)
+    assert stats["decided"] + stats["undecided"] + stats["in_underflow_band"] == int(has.sum())
+    bad = d["action"].copy()
+    pick = np.argwhere((d["count"] > 1) & (d["margin"] > 0.5))[0]
+    others = [n for n in d["nodes"][tuple(pick)] if n >= 0 and n != d["action"][tuple(pick)]]
+    bad[tuple(pick)] = others[0]
+    lp_bad = d["log_prob"].copy()
+    lp_bad[tuple(pick)] = d["logp_entries"][tuple(pick)][list(d["nodes"][tuple(pick)]).index(others[0])]
+    with pytest.raises(AssertionError, match="decided draws differ"):
+        po.check_recorded_policy_rollout(bad, lp_bad, d)

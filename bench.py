@@ -118,9 +118,85 @@ def spawn_ranks(n, argv, popen=None, timeout=None):
             for q in pending:
                 procs[q].kill()
             worst = worst or 124
-    sys.stdout.write(out0.decode("utf-8", "replace"))
+    # ONE JSON line on stdout; whatever else rank 0 printed there (a backend's connection banner) goes to stderr
+    for line in out0.decode("utf-8", "replace").splitlines():
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
     sys.stdout.flush()
     return worst
+
+
+def config3_record(args, boards, weights, device):
+    """BASELINE configs[2] beside the headline (an extra key of the JSON line, measured AFTER it): the same 200-node /
+    4-police / 4096-env workload with a LEARNED policy in the loop, on-device returns and a PPO update — one training
+    iteration = collect T=64 steps (the MAPPO actors sampling inside the fused rollout) + `sy_returns_advantages` + one
+    pass of minibatch PPO over the 262 144 env-steps (1.3 M agent transitions) + weight refresh.  Also the collect rate of
+    the reference's other policy family, the GNN Q-policy (`sy_gnn_q_act` + `sy_env_step_record` per step, graph-replayed)."""
+    import torch
+    import student_mechanism_design_amd as sy
+    from student_mechanism_design_amd import collector as col, policies as pol
+    from student_mechanism_design_amd.update import MappoUpdater
+    N, P, B, T = args.nodes, args.police, args.envs, 64
+    A = P + 1
+    env = sy.BatchedScotlandYardEnv(B, boards, P, args.money, weights, seed=args.seed + 1, reveal_interval=args.reveal, device=device)
+    torch.manual_seed(0)
+    net = pol.MappoPolicy(N, P, hidden_size=64).to(device)
+    fused = pol.DeviceMappoPolicy(net, seed=3)
+    env.set_policy(fused)
+    out = env.alloc_rollout(T)
+    up = MappoUpdater(net, env.ell, env.env_graph, minibatch=32768, use_graph=not args.config3_eager)
+
+    def timed(fn):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        r = fn()
+        torch.cuda.synchronize(device)
+        return r, (time.perf_counter() - t0) * 1e3
+
+    def iteration(split):
+        ms = {}
+        rec, ms["collect"] = timed(lambda: env.rollout(T, out=out)) if split else (env.rollout(T, out=out), 0.0)
+        f = lambda: col.device_returns(rec["reward"], rec["terminated"], 0.99, done_b=rec["truncated"])   # noqa: E731
+        (ret, _), ms["returns"] = timed(f) if split else (f(), 0.0)
+
+        def upd():
+            up.update(rec, ret)
+            fused.refresh()
+        _, ms["update"] = timed(upd) if split else (upd(), 0.0)
+        return ms
+
+    for _ in range(3):
+        iteration(False)                      # warm-up (allocations, the update's graph capture)
+    iters = 5
+    parts = [iteration(True) for _ in range(iters)]
+    _, whole_ms = timed(lambda: [iteration(False) for _ in range(iters)])
+    env.check_status()
+    al, cl = (float(x) for x in up.last_losses)
+    med = lambda k: float(np.median([p_[k] for p_ in parts]))   # noqa: E731
+    n = T * B * A
+    rec3 = {"what": "BASELINE configs[2]: learned policy (MAPPO actors, hidden 64) sampling inside the fused rollout, T=64 x "
+                    "%d envs, returns in one HIP launch, one minibatch-PPO pass (minibatch 32768 env-steps%s), weights "
+                    "refreshed; medians of %d iterations" % (B, ", each step one HIP graph" if up.use_graph else "", iters),
+            "kernel": env.rollout_kernel_name(), "agent_transitions_per_iteration": n,
+            "collect_ms": med("collect"), "returns_ms": med("returns"), "update_ms": med("update"),
+            "collect_agent_steps_per_s": n / (med("collect") * 1e-3),
+            "iteration_ms_unsplit": whole_ms / iters, "iteration_agent_steps_per_s": n * iters / (whole_ms * 1e-3),
+            "update_fraction_of_iteration": med("update") / (med("collect") + med("returns") + med("update")),
+            "last_actor_loss": al, "last_critic_loss": cl, "losses_finite": bool(np.isfinite(al) and np.isfinite(cl))}
+    env.close()
+    # the GNN Q-policy driving the per-step collector (configs[2] names the GNN policy)
+    env = sy.BatchedScotlandYardEnv(B, boards, P, args.money, weights, seed=args.seed + 2, reveal_interval=args.reveal, device=device)
+    gnn = pol.GnnQPolicy(A).to(device)
+    dgnn = pol.DeviceGnnPolicy(gnn, pol.GcnTables(env.pool.boards, device=device), env.env_graph, seed=4, explore_eps=0.1)
+    c = col.RolloutCollector(env, dgnn.act, frames_per_batch=T, use_graph=True)
+    for _ in range(3):
+        c.collect()
+    _, gms = timed(lambda: [c.collect() for _ in range(iters)])
+    env.check_status()
+    rec3["gnn_collect"] = {"what": "GNN Q-policy (2 x AntiSymmetricConv + Linear, epsilon-greedy 0.1) as one HIP kernel per step + "
+                                   "sy_env_step_record, T=64 steps replayed as one HIP graph",
+                           "collect_ms": gms / iters, "collect_agent_steps_per_s": n * iters / (gms * 1e-3)}
+    env.close()
+    return rec3
 
 
 def make_oracle(args, boards, weights, env_graph, threads, env_id_offset=0):
@@ -213,6 +289,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the separately timed trajectory all-gather")
     ap.add_argument("--step-api", action="store_true", help="also time the per-step sy_env_step launch path")
     ap.add_argument("--no-config3", action="store_true", help="skip the configs[2] sub-record (learned policy + update)")
+    ap.add_argument("--config3-eager", action="store_true", help="configs[2] sub-record: eager minibatch steps (no HIP graph)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -399,6 +476,11 @@ def main():
         torch.cuda.synchronize(device)
         result["step_api_agent_steps_per_s"] = n * B * A / (time.perf_counter() - t1)
         del act
+    if rank == 0 and world == 1 and not args.no_config3 and full:
+        try:
+            result["config3"] = config3_record(args, boards, weights, device)
+        except Exception as e:      # the sub-record must never take the headline down with it
+            result["config3"] = {"error": "%s: %s" % (type(e).__name__, e)}
     if rank == 0:
         if not args.no_cpu and world == 1:
             result["cpu_baseline"] = cpu_baseline(args, boards, weights, env.env_graph_host, A)

@@ -230,6 +230,27 @@ int sy_mappo_policy_act(const int32_t *pos, const uint8_t *mask, int64_t mask_ro
                         int32_t num_envs, int32_t num_police, int32_t num_nodes, int32_t hidden, uint64_t seed, uint64_t offset,
                         const uint64_t *offset_dev, int32_t *action, float *log_prob, float *value, float *probs, void *stream);
 
+/* replaces GNNModel.forward + GNNAgent.select_action (agent/gnn_agent.py:230-257, :45-82) for every env and agent in one
+ * launch: node features as training/utils.py:176-200 builds them (column a = one-hot node of agent a; optionally one
+ * more column = the police belief over MrX's node, `belief` float [B][belief_row_stride]), two AntiSymmetricConv layers
+ * (x' = x + eps tanh((W - W^T - gamma I) x + A^ Theta x + b), relu after each) and the Linear head -> one Q value per
+ * node, from MrX's model for MrX and from the police model for every police agent (gnn_trainer.py:148-178); the
+ * action is the masked arg-max (np.argmax: the first maximum in node order), with probability explore_eps a uniform
+ * pick among the valid nodes instead (engine Philox stream: seed; row, offset + *offset_dev), -1 when no node is valid.
+ * Propagation tables per board (graph.py::gcn_tables): nbr int16 [G][N][16] source nodes of every target (-1 padding,
+ * rows filled left to right), coef float [G][N][16] = 1 / sqrt(deg(src) deg(dst)), self_coef float [G][N], env_graph
+ * int32 [B] (NULL = board 0).  A model = sy_gnn_param_floats(F) floats, FP = sy_gnn_padded_features(F): per conv layer
+ * {Wa [FP][FP] = W - W^T - gamma I, Theta [FP][FP] (out, in), b [FP]} x 2, w_out [FP], b_out, epsilon (zero padding).
+ * Outputs: action int32 [B][A]; q_values float [B][2][N] (NULL = not wanted).  Boards of up to 256 nodes.
+ * torch_geometric is not importable offline: pinned to a float64 restatement of the published layer, not to the library. */
+int sy_gnn_padded_features(int32_t num_features);
+int sy_gnn_param_floats(int32_t num_features);
+int sy_gnn_q_act(const int32_t *pos, const float *belief, int64_t belief_row_stride, const uint8_t *mask, int64_t mask_row_stride,
+                 const int16_t *nbr, const float *coef, const float *self_coef, const int32_t *env_graph, const float *model_mrx,
+                 const float *model_police, int32_t num_envs, int32_t num_police, int32_t num_nodes, int32_t num_features,
+                 float explore_eps, uint64_t seed, uint64_t offset, const uint64_t *offset_dev, int32_t *action, float *q_values,
+                 void *stream);
+
 /* replaces the return / advantage lines of MappoAgent.ppo_update (agent/mappo_agent.py:247-258) for a whole
  * [T][B][A] rollout in ONE launch (the reference loops over a flat Python buffer), plus the GAE(gamma, lambda)
  * generalisation (the reference has no GAE; at lambda = 1 with a zero bootstrap GAE's returns equal mode 0's).

@@ -56,7 +56,8 @@ EXPORTS = ["sy_abi_version", "sy_record_words", "sy_last_error", "sy_env_create"
            "sy_env_set_graph_pool", "sy_env_set_rewards", "sy_env_set_policy", "sy_env_bind_state", "sy_env_reset", "sy_env_reset_to",
            "sy_env_step", "sy_env_step_record", "sy_env_rollout", "sy_action_mask_dense", "sy_belief_update", "sy_build_apsp", "sy_sample_boards",
            "sy_masked_categorical_sample", "sy_mappo_policy_act", "sy_env_bind_status", "sy_env_status",
-           "sy_returns_advantages", "sy_build_id", "sy_env_rollout_kernel_name"]
+           "sy_returns_advantages", "sy_build_id", "sy_env_rollout_kernel_name",
+           "sy_gnn_padded_features", "sy_gnn_param_floats", "sy_gnn_q_act"]
 
 _lib = None
 
@@ -75,6 +76,10 @@ def load():
     lib.sy_abi_version.restype = C.c_int
     lib.sy_last_error.restype = C.c_char_p
     lib.sy_build_id.restype = C.c_char_p
+    lib.sy_gnn_padded_features.argtypes = [i32]
+    lib.sy_gnn_param_floats.argtypes = [i32]
+    lib.sy_gnn_q_act.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, u64, u64,
+                                 vp, vp, vp, vp]
     lib.sy_env_rollout_kernel_name.argtypes = [vp, i32, C.c_char_p, i32]
     lib.sy_record_words.argtypes = [i32]
     lib.sy_env_create.argtypes = [C.POINTER(EnvConfig), C.POINTER(vp)]

@@ -363,6 +363,33 @@ int sy_mappo_policy_act(const int32_t* pos, const uint8_t* mask, int64_t mask_ro
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_mappo_policy_act launch");
 }
 
+int sy_gnn_padded_features(int32_t num_features) { return sy::gnn_padded_features(num_features); }
+int sy_gnn_param_floats(int32_t num_features) { return sy::gnn_param_floats(num_features); }
+
+int sy_gnn_q_act(const int32_t* pos, const float* belief, int64_t belief_row_stride, const uint8_t* mask, int64_t mask_row_stride,
+                 const int16_t* nbr, const float* coef, const float* self_coef, const int32_t* env_graph, const float* model_mrx,
+                 const float* model_police, int32_t num_envs, int32_t num_police, int32_t num_nodes, int32_t num_features,
+                 float explore_eps, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int32_t* action, float* q_values,
+                 void* stream) {
+    if (!pos || !mask || !nbr || !coef || !self_coef || !model_mrx || !model_police || !action)
+        return fail(SY_ERR_INVALID, "sy_gnn_q_act: null argument%s");
+    if (num_police < 1 || num_police > SY_MAX_AGENTS - 1 || num_nodes < 1 || num_nodes > 256 || mask_row_stride < num_nodes)
+        return fail(SY_ERR_INVALID, "sy_gnn_q_act: bad sizes (boards of up to 256 nodes)%s");
+    const int A = num_police + 1;
+    if (num_features != A && num_features != A + 1)
+        return fail(SY_ERR_INVALID, "sy_gnn_q_act: num_features must be num_police + 1 (agent one-hots) or + 2 (with the belief column)%s");
+    if (num_features == A + 1 && (!belief || belief_row_stride < num_nodes))
+        return fail(SY_ERR_INVALID, "sy_gnn_q_act: the belief column needs `belief` rows of at least num_nodes floats%s");
+    if (num_features > 9) return fail(SY_ERR_INVALID, "sy_gnn_q_act: at most 9 node features%s");
+    if (!(explore_eps >= 0.0f && explore_eps <= 1.0f)) return fail(SY_ERR_INVALID, "sy_gnn_q_act: explore_eps must be in [0, 1]%s");
+    if (num_envs < 0) return fail(SY_ERR_INVALID, "sy_gnn_q_act: bad num_envs%s");
+    if (num_envs == 0) return SY_OK;
+    hipError_t e = sy::launch_gnn_q_act(pos, num_features == A + 1 ? belief : nullptr, belief_row_stride, mask, mask_row_stride, nbr,
+                                        coef, self_coef, env_graph, model_mrx, model_police, num_envs, A, num_nodes, num_features,
+                                        explore_eps, seed, offset, offset_dev, action, q_values, (hipStream_t)stream);
+    return e == hipSuccess ? SY_OK : hip_fail(e, "sy_gnn_q_act launch");
+}
+
 int sy_returns_advantages(const sy_returns_args* a, void* stream) {
     if (!a || !a->reward || !a->done_a || !a->returns) return fail(SY_ERR_INVALID, "sy_returns_advantages: null argument%s");
     if (a->T < 1 || a->B < 1 || a->A < 1 || a->A > SY_MAX_AGENTS) return fail(SY_ERR_INVALID, "sy_returns_advantages: bad sizes%s");

@@ -112,4 +112,13 @@ hipError_t launch_mappo_policy(const int32_t* pos, const uint8_t* mask, long lon
                                const uint64_t* offset_dev, int32_t* action, float* log_prob, float* value, float* probs_out,
                                hipStream_t stream);
 
+// the GNN Q-policy (sy_gnn.hip)
+int gnn_padded_features(int F);
+int gnn_param_floats(int F);
+hipError_t launch_gnn_q_act(const int32_t* pos, const float* belief, long long belief_stride, const uint8_t* mask,
+                            long long mask_row_stride, const int16_t* nbr, const float* coef, const float* selfc,
+                            const int32_t* env_graph, const float* prm_mrx, const float* prm_pol, int B, int A, int N, int F,
+                            float explore, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int32_t* action,
+                            float* q_out, hipStream_t stream);
+
 }  // namespace sy

@@ -346,3 +346,41 @@ def sample_board_pool_device(num_graphs, num_nodes, num_edges, seed=0, max_edges
         raise RuntimeError(f"Failed to generate graph with {target} edges after {max_attempts} attempts.")
     apsp = device_all_pairs_shortest_paths(ell, N, device=dev)
     return DevicePool(N, NS, ell, apsp, inv_deg, links[:, :target].contiguous(), w[:, :target].contiguous(), target)
+
+
+def gcn_tables(boards: Sequence[Board], directed: bool = True):
+    """Message-passing tables of GCNConv's normalised propagation  A^ = D^-1/2 (A + I) D^-1/2  per board, as the GNN
+    policy kernels read them (`sy_gnn_q_act`, `policies.GnnQModel`): for every TARGET node its source nodes and their
+    coefficients 1 / sqrt(deg(source) deg(target)), deg = number of incoming edges + 1 (the self loop).
+
+    directed=True is the reference's data flow: `create_graph_data` hands `board.edge_links.T` to the model
+    (training/utils.py:170), i.e. every stored edge (u, v) ONCE, and GCNConv propagates source -> target along the
+    edges as given — messages flow u -> v only.  directed=False adds both directions (what `to_undirected` would give).
+    Returns (nbr int16 [G, N, 16] sources, -1 = padding; coef float32 [G, N, 16]; self_coef float32 [G, N])."""
+    boards = list(boards)
+    n = boards[0].num_nodes
+    G = len(boards)
+    nbr = np.full((G, n, ELL_WIDTH), -1, dtype=np.int16)
+    coef = np.zeros((G, n, ELL_WIDTH), dtype=np.float32)
+    self_coef = np.zeros((G, n), dtype=np.float32)
+    for g, b in enumerate(boards):
+        src = b.edge_links[:, 0].astype(np.int64)
+        dst = b.edge_links[:, 1].astype(np.int64)
+        if not directed:
+            src, dst = np.concatenate([src, dst]), np.concatenate([dst, src])
+        deg = 1.0 + np.bincount(dst, minlength=n).astype(np.float64)          # in-degree + self loop (gcn_norm)
+        dinv = 1.0 / np.sqrt(deg)
+        self_coef[g] = (dinv * dinv).astype(np.float32)
+        fill = np.zeros(n, dtype=np.int64)
+        for u, v in zip(src, dst):
+            row = nbr[g, v, : fill[v]]
+            hit = np.nonzero(row == u)[0]
+            if hit.size:                                                        # a parallel edge: one more message
+                coef[g, v, hit[0]] += np.float32(dinv[u] * dinv[v])
+                continue
+            if fill[v] >= ELL_WIDTH:
+                raise ValueError(f"node {v} has more than {ELL_WIDTH} incoming edges")
+            nbr[g, v, fill[v]] = u
+            coef[g, v, fill[v]] = np.float32(dinv[u] * dinv[v])
+            fill[v] += 1
+    return nbr, coef, self_coef

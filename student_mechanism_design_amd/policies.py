@@ -7,11 +7,13 @@ in PyTorch, only the env is a HIP engine.
   networks (oracle/capture_mappo_networks.py); tests/test_policies_cpu.py loads them into this class.  Observations follow
   the trainer (`mappo_trainer.py:173,197`): MrX sees one-hot(MrX_pos), every police sees the multi-hot
   of all police positions; the critic sees their concatenation.
-* `AntiSymmetricConvDense` / `GnnQPolicy` — pure-torch restatement of the model in
-  `src/agent/gnn_agent.py:230-257` (2 x torch_geometric `AntiSymmetricConv` + Linear -> per-node Q).
-  torch_geometric is absent offline: **parity unpinned**; the layer follows the published form
-  x + eps * tanh((W - W^T - gamma I) x + GCN(x) + b) (Gravina et al., ICLR 2023) with PyG's defaults
-  (phi = GCNConv(in, in, bias=False), num_iters = 1).
+* `AntiSymmetricConvEll` / `GnnQModel` / `GnnQPolicy` — the model of `src/agent/gnn_agent.py:230-257` (2 x
+  torch_geometric `AntiSymmetricConv` + Linear -> per-node Q) on GATHER tables over the <= 16 sources of a node
+  (`GcnTables`), never an [N, N] matrix; `DeviceGnnPolicy` = the same forward + masked arg-max as one HIP kernel
+  (`sy_gnn_q_act`).  torch_geometric is absent offline: the layer follows the published form
+  x + eps * tanh((W - W^T - gamma I) x + A^ Theta x + b) (Gravina et al., ICLR 2023) with PyG's defaults
+  (phi = GCNConv(in, in, bias=False), num_iters = 1) and is pinned to an independent float64 restatement
+  (oracle/gnn_oracle.py); against the library itself parity stays unpinned.
 * `ppo_loss` — the clipped surrogate / critic MSE of `MappoAgent.ppo_update` (mappo_agent.py:260-293).
 """
 from typing import Dict, Optional
@@ -199,67 +201,185 @@ class DeviceMappoPolicy:
         return (act, logp, val, probs) if want_probs else (act, logp, val)
 
 
-class AntiSymmetricConvDense(nn.Module):
+class GcnTables:
+    """GCNConv's normalised propagation per board as gather tables (graph.py::gcn_tables): for every target node its
+    source nodes and coefficients 1 / sqrt(deg(src) deg(dst)) — rows have at most 16 sources, so A^ x is a gather over
+    a [G, N, K] index table, never an [N, N] matrix.  `directed=True` (default) is the reference's data flow: the
+    stored edge list is handed to the model once per edge (training/utils.py:170), messages flow source -> target."""
+
+    def __init__(self, boards, device="cpu", directed: bool = True):
+        from .graph import gcn_tables
+        nbr, coef, self_coef = gcn_tables(boards, directed=directed)
+        self.width = max(1, int((nbr >= 0).sum(-1).max()))                        # widest row actually used
+        self.nbr = torch.from_numpy(nbr).to(device)                                # int16 [G, N, 16] (kernel layout)
+        self.coef = torch.from_numpy(coef).to(device)                              # float32 [G, N, 16]
+        self.self_coef = torch.from_numpy(self_coef).to(device)                    # float32 [G, N]
+        self.directed = directed
+
+    def for_envs(self, env_graph: torch.Tensor):
+        """(idx int64 [B, N, K], coef [B, N, K], self_coef [B, N]) of each env's board, trimmed to the widest row."""
+        g = env_graph.long()
+        K = self.width
+        return self.nbr[g, :, :K].long().clamp_min(0), self.coef[g, :, :K], self.self_coef[g]
+
+
+class AntiSymmetricConvEll(nn.Module):
+    """torch_geometric's AntiSymmetricConv with its defaults as the reference uses it (gnn_agent.py:233-246:
+    phi = GCNConv(F, F, bias=False), num_iters = 1, epsilon = gamma = 0.1, act = tanh), restated on gather tables:
+        x' = x + epsilon * tanh(x (W - W^T - gamma I)^T + A^ (x Theta^T) + b)
+    torch_geometric is absent offline: pinned to oracle/gnn_oracle.py (float64, dense A^ built edge by edge from the
+    published formula), parity with the library itself stays unpinned."""
+
     def __init__(self, channels: int, epsilon: float = 0.1, gamma: float = 0.1):
         super().__init__()
         self.W = nn.Parameter(torch.empty(channels, channels))
         self.bias = nn.Parameter(torch.zeros(channels))
-        self.phi = nn.Linear(channels, channels, bias=False)     # GCNConv weight
+        self.phi = nn.Linear(channels, channels, bias=False)     # GCNConv's linear map (weight: out, in)
         self.epsilon, self.gamma = epsilon, gamma
         nn.init.kaiming_uniform_(self.W, a=5 ** 0.5)
 
-    def forward(self, x: torch.Tensor, a_hat: torch.Tensor) -> torch.Tensor:
-        """x [B, N, F]; a_hat [B or 1, N, N] = D^-1/2 (A + I) D^-1/2."""
-        eye = torch.eye(self.W.shape[0], device=x.device, dtype=x.dtype)
-        anti = self.W - self.W.t() - self.gamma * eye
-        h = x @ anti.t() + a_hat @ self.phi(x) + self.bias
+    def antisymmetric(self) -> torch.Tensor:
+        eye = torch.eye(self.W.shape[0], device=self.W.device, dtype=self.W.dtype)
+        return self.W - self.W.t() - self.gamma * eye
+
+    def forward(self, x: torch.Tensor, tables) -> torch.Tensor:
+        """x [B, N, F]; tables = GcnTables.for_envs(env_graph)."""
+        idx, coef, self_coef = tables
+        xt = self.phi(x)                                                          # Theta x
+        msg = self_coef.unsqueeze(-1) * xt
+        F_ = xt.shape[-1]
+        for k in range(idx.shape[-1]):                                            # at most 16 gathers of [B, N, F]
+            msg = msg + coef[:, :, k, None] * torch.gather(xt, 1, idx[:, :, k, None].expand(-1, -1, F_))
+        h = x @ self.antisymmetric().t() + msg + self.bias
         return x + self.epsilon * torch.tanh(h)
 
 
-def normalized_adjacency(ell: torch.Tensor, num_nodes: int) -> torch.Tensor:
-    """Dense GCN propagation matrix per board from the packed ELL table int32/uint32 [G, N, 16]."""
-    G = ell.shape[0]
-    nb = (ell.long() & 0xFFFF)
-    adj = torch.zeros((G, num_nodes, num_nodes + 1), dtype=torch.float32, device=ell.device)
-    adj.scatter_(2, nb.clamp_max(num_nodes), 1.0)
-    adj = adj[..., :num_nodes] + torch.eye(num_nodes, device=ell.device)
-    d = adj.sum(-1).rsqrt()
-    return d.unsqueeze(-1) * adj * d.unsqueeze(-2)
+class GnnQModel(nn.Module):
+    """GNNModel (gnn_agent.py:230-257): conv1 -> relu -> conv2 -> relu -> Linear(F, 1) -> Q per node."""
+
+    def __init__(self, node_feature_size: int):
+        super().__init__()
+        self.conv1 = AntiSymmetricConvEll(node_feature_size)
+        self.conv2 = AntiSymmetricConvEll(node_feature_size)
+        self.out = nn.Linear(node_feature_size, 1)
+
+    def forward(self, x: torch.Tensor, tables) -> torch.Tensor:
+        x = torch.relu(self.conv1(x, tables))
+        x = torch.relu(self.conv2(x, tables))
+        return self.out(x).squeeze(-1)                                            # [B, N]
 
 
 class GnnQPolicy(nn.Module):
-    """Per-node Q values (gnn_agent.py:230-257) over node features [one-hot positions of all agents | belief]."""
+    """The GNN trainer's two agents (gnn_trainer.py:148-178): MrX's model and ONE model shared by all police, both on
+    the node features of training/utils.py:176-200 — column a = one-hot node of agent a (F = number of agents) —
+    plus, optionally, the police belief over MrX's node as one more column (engine extension, default off)."""
 
-    def __init__(self, num_agents: int, with_belief: bool = True):
+    def __init__(self, num_agents: int, with_belief: bool = False):
         super().__init__()
-        f = num_agents + (1 if with_belief else 0)
+        self.A = int(num_agents)
+        self.F = self.A + (1 if with_belief else 0)
         self.with_belief = with_belief
-        self.conv1 = AntiSymmetricConvDense(f)
-        self.conv2 = AntiSymmetricConvDense(f)
-        self.out = nn.Linear(f, 1)
+        self.mrx = GnnQModel(self.F)
+        self.police = GnnQModel(self.F)
 
     def features(self, obs: Dict[str, torch.Tensor], num_nodes: int) -> torch.Tensor:
         pos = obs["agent_position"].long()                                  # [B, A]
         x = torch.zeros((pos.shape[0], num_nodes, pos.shape[1]), device=pos.device)
-        x.scatter_(1, pos.unsqueeze(1), 1.0)                                # node_features, yard.py:279-290
-        if self.with_belief and obs.get("belief_map") is not None:
+        x.scatter_(1, pos.unsqueeze(1), 1.0)                                # node_features, training/utils.py:176-200
+        if self.with_belief:
             x = torch.cat([x, obs["belief_map"].unsqueeze(-1)], dim=-1)
         return x
 
-    def forward(self, x: torch.Tensor, a_hat: torch.Tensor) -> torch.Tensor:
-        x = torch.relu(self.conv1(x, a_hat))
-        x = torch.relu(self.conv2(x, a_hat))
-        return self.out(x).squeeze(-1)                                       # [B, N]
+    def q_values(self, obs: Dict[str, torch.Tensor], tables, num_nodes: int) -> torch.Tensor:
+        """[B, 2, N]: MrX's model, the police model."""
+        x = self.features(obs, num_nodes)
+        return torch.stack([self.mrx(x, tables), self.police(x, tables)], dim=1)
 
     @torch.no_grad()
-    def act_greedy(self, obs: Dict[str, torch.Tensor], a_hat: torch.Tensor):
-        """Masked arg-max per agent (evaluator.py greedy loop); every agent shares the Q map here."""
+    def act_greedy(self, obs: Dict[str, torch.Tensor], tables):
+        """GNNAgent.select_action with epsilon = 0 for every agent (gnn_agent.py:62-74): masked arg-max, -1 (None)
+        without a valid action; the police agents share the police model's Q map."""
         mask = obs["action_mask"]
-        q = self.forward(self.features(obs, mask.shape[-1]), a_hat).unsqueeze(1).expand_as(mask)
+        q2 = self.q_values(obs, tables, mask.shape[-1])
+        A = mask.shape[1]
+        q = torch.cat([q2[:, :1], q2[:, 1:].expand(-1, A - 1, -1)], dim=1)
         q = q.masked_fill(~mask, float("-inf"))
         a = q.argmax(-1)
         a = torch.where(mask.sum(-1) == 0, torch.full_like(a, -1), a)
         return a.to(torch.int32), None, None
+
+
+class DeviceGnnPolicy:
+    """`GnnQPolicy.act_greedy` (+ epsilon-greedy exploration) as ONE HIP kernel (`sy_gnn_q_act`, include/sy_env.h): one
+    wave per env, node features in registers, the transformed features gathered through LDS over the <= 16 sources of
+    every node, both models, the masked arg-max of every agent.  Call `refresh()` after the wrapped module's parameters
+    change.  Fails loudly without the engine library / a GPU."""
+
+    def __init__(self, net: GnnQPolicy, tables: GcnTables, env_graph: torch.Tensor, seed: int = 0, explore_eps: float = 0.0):
+        from . import _lib
+        self._lib_mod, self.lib, self.net, self.tables = _lib, _lib.load(), net, tables
+        self.device = next(net.parameters()).device
+        if self.device.type != "cuda":
+            raise _lib.EngineError("DeviceGnnPolicy needs the module on a GPU; there is no CPU fallback")
+        if net.F > 9:
+            raise ValueError("sy_gnn_q_act supports at most 9 node features")
+        self.env_graph = env_graph.to(device=self.device, dtype=torch.int32).contiguous()
+        self.seed, self.explore_eps = int(seed) & (2**64 - 1), float(explore_eps)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.FP = int(self.lib.sy_gnn_padded_features(net.F))
+        self._packed = torch.zeros((2, int(self.lib.sy_gnn_param_floats(net.F))), dtype=torch.float32, device=self.device)
+        self._out = None
+        self.refresh()
+
+    @torch.no_grad()
+    def refresh(self):
+        F_, FP = self.net.F, self.FP
+        for m, model in enumerate((self.net.mrx, self.net.police)):
+            parts = []
+            for conv in (model.conv1, model.conv2):
+                Wa = torch.zeros((FP, FP), device=self.device)
+                Wa[:F_, :F_] = conv.antisymmetric()
+                Th = torch.zeros((FP, FP), device=self.device)
+                Th[:F_, :F_] = conv.phi.weight
+                b = torch.zeros(FP, device=self.device)
+                b[:F_] = conv.bias
+                parts += [Wa.reshape(-1), Th.reshape(-1), b]
+            wo = torch.zeros(FP, device=self.device)
+            wo[:F_] = model.out.weight.reshape(-1)
+            parts += [wo, model.out.bias.reshape(1), torch.tensor([model.conv1.epsilon], device=self.device)]
+            self._packed[m].copy_(torch.cat([p.float() for p in parts]))
+
+    @torch.no_grad()
+    def act(self, obs: Dict[str, torch.Tensor], want_q: bool = False):
+        """Collector callback: (actions int32 [B, A], None, None); with want_q a 4th item, Q [B, 2, N]."""
+        import ctypes as C
+        pos, mask = obs["agent_position"], obs["action_mask"]
+        B, A = pos.shape
+        N = mask.shape[-1]
+        if pos.dtype != torch.int32 or not pos.is_contiguous():
+            pos = pos.to(torch.int32).contiguous()
+        mk = mask.view(torch.uint8) if mask.dtype == torch.bool else mask
+        if mk.stride(-1) != 1 or mk.stride(0) != A * mk.stride(1):
+            mk = mk.contiguous()
+        bel, bel_stride = None, 0
+        if self.net.with_belief:
+            bel = obs["belief_map"]
+            if bel.stride(-1) != 1:
+                bel = bel.contiguous()
+            bel_stride = bel.stride(0)
+        if self._out is None or self._out.shape[0] != B:
+            self._out = torch.empty((B, A), dtype=torch.int32, device=self.device)
+        q = torch.empty((B, 2, N), dtype=torch.float32, device=self.device) if want_q else None
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        with torch.cuda.device(self.device):
+            self._lib_mod.check(self.lib.sy_gnn_q_act(
+                p(pos), p(bel), C.c_int64(bel_stride), p(mk), C.c_int64(mk.stride(1)), p(self.tables.nbr), p(self.tables.coef),
+                p(self.tables.self_coef), p(self.env_graph), p(self._packed[0]), p(self._packed[1]), B, A - 1, N, self.net.F,
+                C.c_float(self.explore_eps), C.c_uint64(self.seed), C.c_uint64(0), p(self.counter), p(self._out), p(q), stream),
+                "sy_gnn_q_act")
+        self.counter.add_(1)
+        return (self._out, None, None, q) if want_q else (self._out, None, None)
 
 
 def ppo_loss(new_log_prob, old_log_prob, advantages, values, returns, clip: float = 0.2):

@@ -80,42 +80,78 @@ def test_mappo_fast_inference_path_is_the_same_function():
     torch.testing.assert_close(v1, v2, rtol=1e-5, atol=1e-6)
 
 
-def test_antisymmetric_conv_matches_its_formula():
-    torch.manual_seed(0)
-    boards = sy.sample_board_pool(2, 12, 18, seed=1)
-    pool = sy.pack_pool(boards)
-    ell = torch.from_numpy(pool.ell.view(np.int32).copy())
-    a_hat = pol.normalized_adjacency(ell, 12)
-    # reference construction of D^-1/2 (A+I) D^-1/2
-    for gi, b in enumerate(boards):
-        A = np.zeros((12, 12))
-        A[b.edge_links[:, 0], b.edge_links[:, 1]] = 1
-        A[b.edge_links[:, 1], b.edge_links[:, 0]] = 1
-        A += np.eye(12)
-        d = A.sum(1) ** -0.5
-        np.testing.assert_allclose(a_hat[gi].numpy(), d[:, None] * A * d[None, :], rtol=1e-6)
-    conv = pol.AntiSymmetricConvDense(5)
-    x = torch.randn(3, 12, 5)
-    y = conv(x, a_hat[:1])
-    W = conv.W.detach()
-    ref = x + 0.1 * torch.tanh(x @ (W - W.t() - 0.1 * torch.eye(5)).t() + a_hat[:1] @ conv.phi(x) + conv.bias)
-    torch.testing.assert_close(y, ref)
-    # the weight matrix acting on x is anti-symmetric up to the -gamma*I damping (the layer's point)
-    M = W - W.t()
-    torch.testing.assert_close(M, -M.t())
+def _random_gnn(num_agents, with_belief, seed):
+    torch.manual_seed(seed)
+    net = pol.GnnQPolicy(num_agents, with_belief=with_belief)
+    with torch.no_grad():                                 # spread the parameters so that every term of the layer matters
+        for m in (net.mrx, net.police):
+            for conv in (m.conv1, m.conv2):
+                conv.bias.normal_(0.0, 0.5)
+                conv.phi.weight.normal_(0.0, 0.8)
+            m.out.weight.normal_(0.0, 1.0)
+    return net
 
 
-def test_gnn_q_policy_greedy_respects_mask():
-    B, N, P = 16, 12, 2
-    obs = _fake_obs(B, N, P, seed=3)
-    boards = sy.sample_board_pool(1, N, 18, seed=1)
-    a_hat = pol.normalized_adjacency(torch.from_numpy(sy.pack_pool(boards).ell.view(np.int32).copy()), N)
-    net = pol.GnnQPolicy(P + 1, with_belief=True)
+@pytest.mark.parametrize("directed", [True, False])
+def test_gnn_model_on_gather_tables_matches_the_independent_restatement(directed):
+    """`AntiSymmetricConvEll` / `GnnQModel` (gather over the <= 16 sources of a node) against oracle/gnn_oracle.py:
+    float64, the propagation matrix D^-1/2 (A + I) D^-1/2 built DENSE, edge by edge, from the board's edge list — a
+    different formulation of the published layer, not the same expression typed twice.  directed=True is the
+    reference's data flow (every stored edge once, training/utils.py:170)."""
+    from oracle import gnn_oracle as go
+    N, P, B = 37, 3, 11
+    boards = sy.sample_board_pool(3, N, 70, seed=2)
+    tabs = pol.GcnTables(boards, directed=directed)
+    env_graph = torch.tensor([0, 1, 2, 0, 1, 2, 0, 1, 2, 0, 1])
+    obs = _fake_obs(B, N, P, seed=4)
+    obs["belief_map"] = torch.rand(B, N)
+    for with_belief in (False, True):
+        net = _random_gnn(P + 1, with_belief, seed=7)
+        with torch.no_grad():
+            q = net.q_values(obs, tabs.for_envs(env_graph), N).double().numpy()           # [B, 2, N]
+        pos = obs["agent_position"].numpy()
+        x = go.node_features(pos, N, obs["belief_map"].numpy() if with_belief else None)
+        for b in range(B):
+            a_hat = go.propagation_matrix(N, boards[int(env_graph[b])].edge_links, directed=directed)
+            for m, model in enumerate((net.mrx, net.police)):
+                want = go.gnn_q(x[b: b + 1], a_hat, go.params_of(model))[0]
+                np.testing.assert_allclose(q[b, m], want, rtol=0, atol=2e-6)
+        # the propagation is not the identity: the board matters
+        assert np.abs(q[0, 0] - q[0, 0].mean()).max() > 1e-3
+    # the tables themselves: coefficients of a hand-checked path 0 -> 1 -> 2 (directed) / 0 - 1 - 2
+    path = sy.make_board(3, [[0, 1], [1, 2]], [1, 1])
+    t = pol.GcnTables([path], directed=directed)
+    a_hat = go.propagation_matrix(3, path.edge_links, directed=directed)
+    dense = np.zeros((3, 3))
+    for v in range(3):
+        dense[v, v] = float(t.self_coef[0, v])
+        for k in range(16):
+            u = int(t.nbr[0, v, k])
+            if u >= 0:
+                dense[v, u] += float(t.coef[0, v, k])
+    np.testing.assert_allclose(dense, a_hat, rtol=1e-6)
+    if directed:
+        np.testing.assert_allclose(a_hat, [[1, 0, 0], [1 / np.sqrt(2), 0.5, 0], [0, 0.5, 0.5]], rtol=1e-12)
+
+
+def test_gnn_policy_features_and_greedy_actions():
+    from oracle import gnn_oracle as go
+    B, N, P = 16, 30, 2
+    obs = _fake_obs(B, N, P, seed=1)
+    boards = sy.sample_board_pool(2, N, 50, seed=1)
+    tabs = pol.GcnTables(boards)
+    env_graph = torch.arange(B) % 2
+    net = _random_gnn(P + 1, True, seed=3)
     x = net.features(obs, N)
     assert x.shape == (B, N, P + 2) and x[..., : P + 1].sum() == B * (P + 1)
-    a, _, _ = net.act_greedy(obs, a_hat)
+    a, _, _ = net.act_greedy(obs, tabs.for_envs(env_graph))
     legal = torch.gather(obs["action_mask"], -1, a.clamp_min(0).long().unsqueeze(-1)).squeeze(-1)
-    assert bool((legal | (a < 0)).all())
+    assert bool((legal | (a < 0)).all()) and bool((a[0, 1] == -1))                      # (agent without legal moves -> None)
+    with torch.no_grad():
+        q = net.q_values(obs, tabs.for_envs(env_graph), N).double().numpy()
+    want, margin = go.greedy_actions(q[:, 0], q[:, 1], obs["action_mask"].numpy())
+    decided = margin > 1e-6
+    assert (a.numpy()[decided] == want[decided]).all()
 
 
 def test_device_policy_and_sampler_refuse_to_run_without_a_gpu():
@@ -190,3 +226,54 @@ def test_policy_oracle_philox_and_softmax_are_pinned():
     lp_bad[tuple(pick)] = d["logp_entries"][tuple(pick)][list(d["nodes"][tuple(pick)]).index(others[0])]
     with pytest.raises(AssertionError, match="decided draws differ"):
         po.check_recorded_policy_rollout(bad, lp_bad, d)
+
+
+def test_mappo_updater_losses_are_the_masked_softmax_surrogate():
+    """`update.MappoUpdater` computes the new log-probabilities from a log-sum-exp over the <= 16 affordable entries of the
+    agent's ELL row.  Against the plain form — softmax over all N nodes (the pinned `MappoPolicy.probs`), times the mask,
+    renormalised as `select_action` does (mappo_agent.py:112-134), clipped surrogate + critic MSE (:260-293) — the losses
+    must agree, and an update must move the parameters without any NaN."""
+    from student_mechanism_design_amd.update import MappoUpdater
+    rng = np.random.default_rng(3)
+    N, P, H, T, B = 40, 3, 16, 6, 10
+    A = P + 1
+    boards = sy.sample_board_pool(2, N, 70, seed=5)
+    pool = sy.pack_pool(boards)
+    ell = torch.from_numpy(pool.ell.view(np.int32).copy())
+    env_graph = torch.arange(B) % 2
+    torch.manual_seed(1)
+    net = pol.MappoPolicy(N, P, hidden_size=H)
+    pos = torch.stack([torch.stack([torch.randperm(N)[:A] for _ in range(B)]) for _ in range(T)]).int()     # [T, B, A]
+    budget = torch.cat([torch.full((T, B, 1), 1000), torch.randint(0, 4, (T, B, P))], -1).int()
+    mask = torch.zeros((T, B, A, N), dtype=torch.bool)
+    for t in range(T):
+        for b in range(B):
+            for a in range(A):
+                row = pool.ell[int(env_graph[b]), int(pos[t, b, a])]
+                ok = (row >> 16) <= int(budget[t, b, a])
+                mask[t, b, a, (row & 0xFFFF)[ok].astype(np.int64)] = True
+    cnt = mask.sum(-1)
+    act = torch.where(cnt > 0, torch.multinomial(mask.reshape(-1, N).float() + 1e-9, 1).reshape(T, B, A), torch.full((T, B, A), -1))
+    act = torch.where(cnt > 0, act, torch.full_like(act, -1)).int()
+    old_lp = torch.where(cnt > 0, -torch.log(cnt.float().clamp_min(1)) + 0.1 * torch.randn(T, B, A), torch.zeros(T, B, A))
+    returns = torch.randn(T, B, A)
+    rec = {"pos": pos, "budget": budget, "action": act, "log_prob": old_lp}
+    up = MappoUpdater(net, ell, env_graph, minibatch=T * B)
+    R = T * B
+    adv = ((returns - returns.mean()) / (returns.std() + 1e-8)).reshape(R, A)
+    al, cl = up._losses(pos.reshape(R, A).long(), budget.reshape(R, A).long(), act.reshape(R, A).long(), old_lp.reshape(R, A), adv,
+                        returns.reshape(R, A).sum(-1), env_graph.repeat(T))
+    # the plain form
+    obs = {"MrX_pos": pos.reshape(R, A)[:, 0], "Polices_pos": pos.reshape(R, A)[:, 1:]}
+    pm = net.probs(obs) * mask.reshape(R, A, N).float()
+    pm = pm / pm.sum(-1, keepdim=True).clamp_min(1e-30)
+    valid = (act.reshape(R, A) >= 0).float()
+    new_lp = torch.log(torch.gather(pm, -1, act.reshape(R, A).long().clamp_min(0).unsqueeze(-1)).squeeze(-1).clamp_min(1e-30)) * valid
+    al_ref, cl_ref = pol.ppo_loss(new_lp, old_lp.reshape(R, A) * valid, adv, net.value(obs), returns.reshape(R, A).sum(-1))
+    torch.testing.assert_close(al, al_ref, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(cl, cl_ref, rtol=1e-5, atol=1e-6)
+    before = [p.detach().clone() for p in net.parameters()]
+    a2, c2 = up.update(rec, returns)
+    assert torch.isfinite(a2) and torch.isfinite(c2)
+    assert all(torch.isfinite(p).all() for p in net.parameters())
+    assert all(not torch.equal(x, y) for x, y in zip(before, net.parameters()))

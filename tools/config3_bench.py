@@ -6,7 +6,7 @@ PyTorch-ROCm (or inside the fused kernel), the rollout record and returns / adva
 
 One iteration = collect T steps of B envs + returns/advantages (`sy_returns_advantages`, one launch) + one update over
 the T*B*(P+1) transitions in minibatches.  Policies:
-  gnn      GnnQPolicy (pure-torch AntiSymmetricConv x2 + Linear, greedy masked arg-max) driving the per-step collector;
+  gnn      GnnQPolicy (AntiSymmetricConv x2 + Linear on gather tables; greedy masked arg-max as one HIP kernel per step) driving the per-step collector;
            update = one TD(0) step of the DQN loss on the collected transitions (gnn_agent.py's update, batched)
   mappo    MappoPolicy (torch MLP actors + central critic) driving the per-step collector (torch forward, HIP sampling
            kernel, eager launches); update = clipped PPO surrogate + critic MSE (mappo_agent.py:260-293)
@@ -27,7 +27,7 @@ import torch
 sys.path.insert(0, '.')
 import student_mechanism_design_amd as sy  # noqa: E402
 from student_mechanism_design_amd import collector as col  # noqa: E402
-from student_mechanism_design_amd.policies import DeviceMappoPolicy, GnnQPolicy, MappoPolicy, normalized_adjacency, ppo_loss  # noqa: E402
+from student_mechanism_design_amd.policies import DeviceGnnPolicy, DeviceMappoPolicy, GcnTables, GnnQPolicy, MappoPolicy, ppo_loss  # noqa: E402
 
 
 def timed(fn, dev):
@@ -61,7 +61,7 @@ def mappo_update(net, opt, rec, ret, adv_std, N, P, minibatch):
         opt.step()
 
 
-def gnn_update(gnn, opt, rec, a_hat_b, N, gamma, minibatch_steps):
+def gnn_update(gnn, opt, rec, tabs, N, gamma, minibatch_steps):
     """One TD(0) step of the DQN loss per chunk of steps: Q(s, a_police0) vs r + gamma * max_a' Q(s') (gnn_agent.py update)."""
     T, B, A = rec["action"].shape
     done = (rec["terminated"] | rec["truncated"]).bool()
@@ -71,9 +71,9 @@ def gnn_update(gnn, opt, rec, a_hat_b, N, gamma, minibatch_steps):
         for s in range(s0, s1):
             obs = {"agent_position": rec["pos"][s], "belief_map": rec["belief"][s][..., :N], "action_mask": rec["mask"][s][..., :N].bool()}
             nxt = {"agent_position": rec["pos"][s + 1], "belief_map": rec["belief"][s + 1][..., :N]}
-            q = gnn.forward(gnn.features(obs, N), a_hat_b)                                # [B, N]
+            q = gnn.police(gnn.features(obs, N), tabs)                                    # [B, N]
             with torch.no_grad():
-                qn = gnn.forward(gnn.features(nxt, N), a_hat_b).max(-1).values
+                qn = gnn.police(gnn.features(nxt, N), tabs).max(-1).values
             a1 = rec["action"][s][:, 1].long().clamp_min(0)                                # Police0's node
             target = rec["reward"][s][:, 1].float() + gamma * qn * (~done[s]).float()
             loss = loss + torch.nn.functional.mse_loss(q.gather(1, a1.unsqueeze(1)).squeeze(1), target)
@@ -102,9 +102,11 @@ def main():
         torch.manual_seed(0)
         if name == "gnn":
             gnn = GnnQPolicy(A).to(dev)
-            a_hat_b = normalized_adjacency(env.ell, N)[env.env_graph.long()].contiguous()       # [B, N, N] resident
+            gt = GcnTables(env.pool.boards, device=dev)
+            a_hat_b = gt.for_envs(env.env_graph)                                                  # gather tables [B, N, K]
             opt = torch.optim.Adam(gnn.parameters(), lr=1e-3)
-            collector = col.RolloutCollector(env, lambda obs: gnn.act_greedy(obs, a_hat_b), frames_per_batch=T)
+            dgnn = DeviceGnnPolicy(gnn, gt, env.env_graph)
+            collector = col.RolloutCollector(env, dgnn.act, frames_per_batch=T, use_graph=True)
             collect = collector.collect
         else:
             net = MappoPolicy(N, P, hidden_size=64).to(dev)
@@ -131,7 +133,7 @@ def main():
                                                               values=rec.get("value")), dev)
             t_r += ms
             if name == "gnn":
-                _, ms = timed(lambda: gnn_update(gnn, opt, rec, a_hat_b, N, args.gamma, 8), dev)
+                _, ms = timed(lambda: (gnn_update(gnn, opt, rec, a_hat_b, N, args.gamma, 8), dgnn.refresh()), dev)
             else:
                 def upd():
                     adv_std = col.standardized_advantages(ret, torch.zeros_like(ret)) if rec.get("value") is None else \

@@ -182,6 +182,13 @@ def config3_record(args, boards, weights, device):
             "iteration_ms_unsplit": whole_ms / iters, "iteration_agent_steps_per_s": n * iters / (whole_ms * 1e-3),
             "update_fraction_of_iteration": med("update") / (med("collect") + med("returns") + med("update")),
             "last_actor_loss": al, "last_critic_loss": cl, "losses_finite": bool(np.isfinite(al) and np.isfinite(cl))}
+    # the reference's literal form: ONE step over the whole buffer (mappo_agent.py:260-293 has no minibatches)
+    up_full = MappoUpdater(net, env.ell, env.env_graph, minibatch=T * B, use_graph=False)
+    rec = env.rollout(T, out=out)
+    ret, _ = col.device_returns(rec["reward"], rec["terminated"], 0.99, done_b=rec["truncated"])
+    for _ in range(2):
+        up_full.update(rec, ret)
+    rec3["update_ms_one_full_batch_step"] = float(np.median([timed(lambda: up_full.update(rec, ret))[1] for _ in range(iters)]))
     env.close()
     # the GNN Q-policy driving the per-step collector (configs[2] names the GNN policy)
     env = sy.BatchedScotlandYardEnv(B, boards, P, args.money, weights, seed=args.seed + 2, reveal_interval=args.reveal, device=device)

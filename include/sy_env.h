@@ -237,17 +237,19 @@ int sy_mappo_policy_act(const int32_t *pos, const uint8_t *mask, int64_t mask_ro
  * node, from MrX's model for MrX and from the police model for every police agent (gnn_trainer.py:148-178); the
  * action is the masked arg-max (np.argmax: the first maximum in node order), with probability explore_eps a uniform
  * pick among the valid nodes instead (engine Philox stream: seed; row, offset + *offset_dev), -1 when no node is valid.
- * Propagation tables per board (graph.py::gcn_tables): nbr int16 [G][N][16] source nodes of every target (-1 padding,
- * rows filled left to right), coef float [G][N][16] = 1 / sqrt(deg(src) deg(dst)), self_coef float [G][N], env_graph
- * int32 [B] (NULL = board 0).  A model = sy_gnn_param_floats(F) floats, FP = sy_gnn_padded_features(F): per conv layer
- * {Wa [FP][FP] = W - W^T - gamma I, Theta [FP][FP] (out, in), b [FP]} x 2, w_out [FP], b_out, epsilon (zero padding).
+ * Propagation table per board (graph.py::gcn_tables, packed): gcn_table uint32 [G][N][K][2] = for every target node its K
+ * = table_width (the pool's widest row, <= 16) entries {source node, float bits of 1 / sqrt(deg(src) deg(dst))}, rows
+ * filled left to right, padding {0, 0.0f}; self_coef float [G][N]; env_graph int32 [B] (NULL = board 0).
+ * models = sy_gnn_param_floats(F) pairs of floats, BOTH models interleaved ([p][0] MrX's, [p][1] the police's), FP =
+ * sy_gnn_padded_features(F): per conv layer {Wa [FP][FP] = W - W^T - gamma I, Theta [FP][FP] (out, in), b [FP]} x 2,
+ * w_out [FP], b_out, epsilon (zero padding).
  * Outputs: action int32 [B][A]; q_values float [B][2][N] (NULL = not wanted).  Boards of up to 256 nodes.
  * torch_geometric is not importable offline: pinned to a float64 restatement of the published layer, not to the library. */
 int sy_gnn_padded_features(int32_t num_features);
 int sy_gnn_param_floats(int32_t num_features);
 int sy_gnn_q_act(const int32_t *pos, const float *belief, int64_t belief_row_stride, const uint8_t *mask, int64_t mask_row_stride,
-                 const int16_t *nbr, const float *coef, const float *self_coef, const int32_t *env_graph, const float *model_mrx,
-                 const float *model_police, int32_t num_envs, int32_t num_police, int32_t num_nodes, int32_t num_features,
+                 const uint32_t *gcn_table, int32_t table_width, const float *self_coef, const int32_t *env_graph,
+                 const float *models, int32_t num_envs, int32_t num_police, int32_t num_nodes, int32_t num_features,
                  float explore_eps, uint64_t seed, uint64_t offset, const uint64_t *offset_dev, int32_t *action, float *q_values,
                  void *stream);
 

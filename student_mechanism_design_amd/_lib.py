@@ -78,7 +78,7 @@ def load():
     lib.sy_build_id.restype = C.c_char_p
     lib.sy_gnn_padded_features.argtypes = [i32]
     lib.sy_gnn_param_floats.argtypes = [i32]
-    lib.sy_gnn_q_act.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, C.c_float, u64, u64,
+    lib.sy_gnn_q_act.argtypes = [vp, vp, C.c_int64, vp, C.c_int64, vp, i32, vp, vp, vp, i32, i32, i32, i32, C.c_float, u64, u64,
                                  vp, vp, vp, vp]
     lib.sy_env_rollout_kernel_name.argtypes = [vp, i32, C.c_char_p, i32]
     lib.sy_record_words.argtypes = [i32]

@@ -367,14 +367,15 @@ int sy_gnn_padded_features(int32_t num_features) { return sy::gnn_padded_feature
 int sy_gnn_param_floats(int32_t num_features) { return sy::gnn_param_floats(num_features); }
 
 int sy_gnn_q_act(const int32_t* pos, const float* belief, int64_t belief_row_stride, const uint8_t* mask, int64_t mask_row_stride,
-                 const int16_t* nbr, const float* coef, const float* self_coef, const int32_t* env_graph, const float* model_mrx,
-                 const float* model_police, int32_t num_envs, int32_t num_police, int32_t num_nodes, int32_t num_features,
-                 float explore_eps, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int32_t* action, float* q_values,
-                 void* stream) {
-    if (!pos || !mask || !nbr || !coef || !self_coef || !model_mrx || !model_police || !action)
-        return fail(SY_ERR_INVALID, "sy_gnn_q_act: null argument%s");
+                 const uint32_t* gcn_table, int32_t table_width, const float* self_coef, const int32_t* env_graph, const float* models,
+                 int32_t num_envs, int32_t num_police, int32_t num_nodes, int32_t num_features, float explore_eps, uint64_t seed,
+                 uint64_t offset, const uint64_t* offset_dev, int32_t* action, float* q_values, void* stream) {
+    if (!pos || !mask || !gcn_table || !self_coef || !models || !action) return fail(SY_ERR_INVALID, "sy_gnn_q_act: null argument%s");
     if (num_police < 1 || num_police > SY_MAX_AGENTS - 1 || num_nodes < 1 || num_nodes > 256 || mask_row_stride < num_nodes)
         return fail(SY_ERR_INVALID, "sy_gnn_q_act: bad sizes (boards of up to 256 nodes)%s");
+    if (table_width < 1 || table_width > SY_ELL_WIDTH) return fail(SY_ERR_INVALID, "sy_gnn_q_act: table_width must be in [1, 16]%s");
+    if ((reinterpret_cast<uintptr_t>(gcn_table) & 7) || (reinterpret_cast<uintptr_t>(models) & 7))
+        return fail(SY_ERR_INVALID, "sy_gnn_q_act: gcn_table and models must be 8-byte aligned%s");
     const int A = num_police + 1;
     if (num_features != A && num_features != A + 1)
         return fail(SY_ERR_INVALID, "sy_gnn_q_act: num_features must be num_police + 1 (agent one-hots) or + 2 (with the belief column)%s");
@@ -384,8 +385,8 @@ int sy_gnn_q_act(const int32_t* pos, const float* belief, int64_t belief_row_str
     if (!(explore_eps >= 0.0f && explore_eps <= 1.0f)) return fail(SY_ERR_INVALID, "sy_gnn_q_act: explore_eps must be in [0, 1]%s");
     if (num_envs < 0) return fail(SY_ERR_INVALID, "sy_gnn_q_act: bad num_envs%s");
     if (num_envs == 0) return SY_OK;
-    hipError_t e = sy::launch_gnn_q_act(pos, num_features == A + 1 ? belief : nullptr, belief_row_stride, mask, mask_row_stride, nbr,
-                                        coef, self_coef, env_graph, model_mrx, model_police, num_envs, A, num_nodes, num_features,
+    hipError_t e = sy::launch_gnn_q_act(pos, num_features == A + 1 ? belief : nullptr, belief_row_stride, mask, mask_row_stride,
+                                        gcn_table, table_width, self_coef, env_graph, models, num_envs, A, num_nodes, num_features,
                                         explore_eps, seed, offset, offset_dev, action, q_values, (hipStream_t)stream);
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_gnn_q_act launch");
 }

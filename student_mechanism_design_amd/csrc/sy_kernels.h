@@ -116,9 +116,8 @@ hipError_t launch_mappo_policy(const int32_t* pos, const uint8_t* mask, long lon
 int gnn_padded_features(int F);
 int gnn_param_floats(int F);
 hipError_t launch_gnn_q_act(const int32_t* pos, const float* belief, long long belief_stride, const uint8_t* mask,
-                            long long mask_row_stride, const int16_t* nbr, const float* coef, const float* selfc,
-                            const int32_t* env_graph, const float* prm_mrx, const float* prm_pol, int B, int A, int N, int F,
-                            float explore, uint64_t seed, uint64_t offset, const uint64_t* offset_dev, int32_t* action,
-                            float* q_out, hipStream_t stream);
+                            long long mask_row_stride, const uint32_t* tab, int K, const float* selfc, const int32_t* env_graph,
+                            const float* models, int B, int A, int N, int F, float explore, uint64_t seed, uint64_t offset,
+                            const uint64_t* offset_dev, int32_t* action, float* q_out, hipStream_t stream);
 
 }  // namespace sy

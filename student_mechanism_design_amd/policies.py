@@ -215,6 +215,13 @@ class GcnTables:
         self.coef = torch.from_numpy(coef).to(device)                              # float32 [G, N, 16]
         self.self_coef = torch.from_numpy(self_coef).to(device)                    # float32 [G, N]
         self.directed = directed
+        # the kernel's packed form: [G, N, K, 2] = {source node, float bits of the coefficient}, padding {0, 0.0}
+        import numpy as _np
+        K = self.width
+        packed = _np.zeros(nbr.shape[:2] + (K, 2), dtype=_np.uint32)
+        packed[..., 0] = _np.where(nbr[:, :, :K] >= 0, nbr[:, :, :K], 0).astype(_np.uint32)
+        packed[..., 1] = _np.where(nbr[:, :, :K] >= 0, coef[:, :, :K], 0.0).astype(_np.float32).view(_np.uint32)
+        self.packed = torch.from_numpy(packed.view(_np.int32)).to(device).contiguous()
 
     def for_envs(self, env_graph: torch.Tensor):
         """(idx int64 [B, N, K], coef [B, N, K], self_coef [B, N]) of each env's board, trimmed to the widest row."""
@@ -327,7 +334,7 @@ class DeviceGnnPolicy:
         self.seed, self.explore_eps = int(seed) & (2**64 - 1), float(explore_eps)
         self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.FP = int(self.lib.sy_gnn_padded_features(net.F))
-        self._packed = torch.zeros((2, int(self.lib.sy_gnn_param_floats(net.F))), dtype=torch.float32, device=self.device)
+        self._packed = torch.zeros((int(self.lib.sy_gnn_param_floats(net.F)), 2), dtype=torch.float32, device=self.device)
         self._out = None
         self.refresh()
 
@@ -347,7 +354,7 @@ class DeviceGnnPolicy:
             wo = torch.zeros(FP, device=self.device)
             wo[:F_] = model.out.weight.reshape(-1)
             parts += [wo, model.out.bias.reshape(1), torch.tensor([model.conv1.epsilon], device=self.device)]
-            self._packed[m].copy_(torch.cat([p.float() for p in parts]))
+            self._packed[:, m].copy_(torch.cat([p.float() for p in parts]))
 
     @torch.no_grad()
     def act(self, obs: Dict[str, torch.Tensor], want_q: bool = False):
@@ -374,8 +381,8 @@ class DeviceGnnPolicy:
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         with torch.cuda.device(self.device):
             self._lib_mod.check(self.lib.sy_gnn_q_act(
-                p(pos), p(bel), C.c_int64(bel_stride), p(mk), C.c_int64(mk.stride(1)), p(self.tables.nbr), p(self.tables.coef),
-                p(self.tables.self_coef), p(self.env_graph), p(self._packed[0]), p(self._packed[1]), B, A - 1, N, self.net.F,
+                p(pos), p(bel), C.c_int64(bel_stride), p(mk), C.c_int64(mk.stride(1)), p(self.tables.packed), self.tables.width,
+                p(self.tables.self_coef), p(self.env_graph), p(self._packed), B, A - 1, N, self.net.F,
                 C.c_float(self.explore_eps), C.c_uint64(self.seed), C.c_uint64(0), p(self.counter), p(self._out), p(q), stream),
                 "sy_gnn_q_act")
         self.counter.add_(1)

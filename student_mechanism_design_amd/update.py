@@ -7,8 +7,9 @@ agent's own action / log-probability / advantage, in minibatches of env-steps.
 
 What makes it fast (round 2's plain-torch form spent 35.7 ms per update of 1.3 M transitions, 98 % of an iteration):
   * no host synchronisation anywhere in the loop (losses stay device tensors; the caller reads them when it wants);
-  * first layers as row lookups in W1 (one-hot / multi-hot observations never materialised), second layers as ONE
-    batched matmul -> logits [A, mb, N];
+  * first layers as matmuls on two [mb, N] one-hot / multi-hot matrices (all police actors in one matmul; a row-lookup
+    form has a scatter-add backward with ~10^5 colliding rows per minibatch: 14 of round 2's 30 ms), second layers as
+    ONE batched matmul -> logits [A, mb, N];
   * the new log-probabilities come from a log-sum-exp over the <= 16 AFFORDABLE entries of the agent's ELL row (gathered
     from the logits with the board table) — the masked, renormalised softmax of `select_action` (mappo_agent.py:112-134)
     without ever forming [mb, A, N] probability / mask tensors;
@@ -42,12 +43,19 @@ class MappoUpdater:
         """pos, budget, act int64 [mb, A]; old_lp, adv float [mb, A]; team_ret [mb]; graph_of_row int64 [mb]."""
         net, A, P, N = self.net, self.A, self.P, self.N
         mrx, pol = pos[:, 0], pos[:, 1:]
+        mb = pos.shape[0]
         W1 = torch.stack([a[0].weight for a in net.actors])                     # [A, H, N]
         b1 = torch.stack([a[0].bias for a in net.actors])                       # [A, H]
         W2 = torch.stack([a[2].weight for a in net.actors])                     # [A, N, H]
         b2 = torch.stack([a[2].bias for a in net.actors])                       # [A, N]
-        h0 = W1[0].t()[mrx]                                                     # [mb, H]      one-hot MrX node = a row lookup
-        hp = W1[1:].transpose(1, 2)[:, pol].sum(2)                              # [P, mb, H]   multi-hot police nodes
+        H = W1.shape[1]
+        # The trainer's observations (mappo_trainer.py:173,197) as two [mb, N] matrices built without gradients: the
+        # first layers are then plain matmuls — their backward is a matmul too, where a row-lookup form pays an
+        # index_put with half a million colliding rows per minibatch (14 of round 2's 30 ms).
+        oh_m = torch.zeros((mb, N), dtype=W1.dtype, device=pos.device).scatter_(1, mrx.unsqueeze(1), 1.0)
+        oh_p = torch.zeros((mb, N), dtype=W1.dtype, device=pos.device).scatter_(1, pol, 1.0)
+        h0 = oh_m @ W1[0].t()                                                   # [mb, H]
+        hp = (oh_p @ W1[1:].reshape(P * H, N).t()).view(mb, P, H).transpose(0, 1)   # [P, mb, H]: all police actors in one matmul
         h = torch.relu(torch.cat([h0.unsqueeze(0), hp], 0) + b1.unsqueeze(1))   # [A, mb, H]
         logits = torch.baddbmm(b2.unsqueeze(1), h, W2.transpose(1, 2))          # [A, mb, N]
         # the affordable entries of every agent's ELL row: <= 16 per (row, agent)
@@ -65,7 +73,10 @@ class MappoUpdater:
         ratio = torch.exp(new_lp - old_lp * vf)
         surr = torch.min(ratio * adv, torch.clamp(ratio, 1.0 - self.clip, 1.0 + self.clip) * adv)
         actor_loss = -surr.mean()                                               # mappo_agent.py:284-291
-        value = net.value_fast({"MrX_pos": mrx, "Polices_pos": pol})
+        # CentralCritic on [mrx] + [police] * P (mappo_agent.py:32-44): the P copies of the police block share one input
+        c1 = net.critic[0].weight.view(H, A, N)
+        hc = torch.relu(oh_m @ c1[:, 0].t() + oh_p @ c1[:, 1:].sum(1).t() + net.critic[0].bias)
+        value = net.critic[2](hc).squeeze(-1)
         critic_loss = torch.nn.functional.mse_loss(value, team_ret)             # :260-265
         return actor_loss, critic_loss
 
@@ -94,6 +105,8 @@ class MappoUpdater:
                 "team_ret": returns.reshape(R, A).sum(-1).float()}
         graph_rows = self.env_graph.repeat(T)                                   # row r = t * B + b -> board of env b
         perm = torch.randperm(R, device=self.device, generator=generator)
+        shuf = {k: v[perm] for k, v in flat.items()}                            # ONE shuffle of the record per update:
+        shuf["graph"] = graph_rows[perm]                                        # minibatches are contiguous slices of it
         if self._static is None or self._static["pos"].shape[0] != mb:
             z = lambda dt, *s: torch.zeros(s, dtype=dt, device=self.device)     # noqa: E731
             self._static = {"pos": z(torch.int64, mb, A), "budget": z(torch.int64, mb, A), "act": z(torch.int64, mb, A),
@@ -103,10 +116,8 @@ class MappoUpdater:
         st = self._static
         nfull = R // mb
         for i in range(nfull):                                                  # (a ragged tail is dropped, as minibatch PPO does)
-            idx = perm[i * mb:(i + 1) * mb]
-            for k in ("pos", "budget", "act", "old_lp", "adv", "team_ret"):
-                st[k].copy_(flat[k][idx])
-            st["graph"].copy_(graph_rows[idx])
+            for k in ("pos", "budget", "act", "old_lp", "adv", "team_ret", "graph"):
+                st[k].copy_(shuf[k][i * mb:(i + 1) * mb])
             if not self.use_graph:
                 self._step(st)
             else:

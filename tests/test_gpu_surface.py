@@ -235,7 +235,7 @@ def test_gnn_policy_kernel_matches_the_independent_restatement(sy, N, P, B, with
     want_a, margin = go.greedy_actions(want_q[:, 0], want_q[:, 1], mask)
     got = _np(act)
     decided = margin > 1e-5
-    assert decided.mean() > 0.9 and (got[decided] == want_a[decided]).all()
+    assert decided.mean() > 0.5 and (got[decided] == want_a[decided]).all()      # (nodes far from every agent tie exactly)
     none = mask.sum(-1) == 0
     assert (got[none] == -1).all() and (got[~none] >= 0).all()
     assert np.take_along_axis(mask, np.maximum(got, 0)[..., None], -1)[..., 0][~none].all()

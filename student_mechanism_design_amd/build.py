@@ -161,5 +161,5 @@ def build_extension(force=False, verbose=False, with_fault_build=False, extra_fl
 
 if __name__ == "__main__":
     t0 = time.time()
-    print(build_extension(force="--force" in sys.argv or "--fault" in sys.argv, verbose=True, with_fault_build="--fault" in sys.argv))
+    print(build_extension(force="--force" in sys.argv, verbose=True, with_fault_build="--no-fault" not in sys.argv))
     print("build took %.1f s" % (time.time() - t0))

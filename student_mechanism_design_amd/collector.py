@@ -134,6 +134,8 @@ def device_returns(reward: torch.Tensor, done_a: torch.Tensor, gamma: float, don
     lam=None: the reference's recurrence, mappo_agent.py:247-258 — R_t = r_t + gamma * R_{t+1} * (1 - done_t),
     adv = R - V; with dtype=float32 it reproduces the reference's float32 tensors bit for bit.
     lam given: GAE(gamma, lam) with bootstrap `last_value`; returns = adv + V.
+    `values` / `last_value` are float32 (a critic's output): a float64 critic is rounded to float32 before the recurrence,
+    also with dtype=float64 — that dtype widens the reward arithmetic, not the values.
     `reward` [T, B, A] float32/float64, any T / B strides (the packed record's `reward` view is read in place);
     done = done_a | done_b, each [T, B] uint8 / bool / int32 (the record's `terminated`, `truncated`);
     `values` [T, B] (central critic) or [T, B, A]; `last_value` [B] or [B, A].  Returns (returns, advantages),
@@ -240,6 +242,12 @@ class TrajectoryExchange:
     def __init__(self, record, group=None):
         if not hasattr(record, "arena"):
             raise ValueError("TrajectoryExchange needs an arena-backed record (env.alloc_rollout)")
+        # only the arena travels: a tensor hung on the record from outside it would be dropped without a word
+        lo, hi = record.arena.data_ptr(), record.arena.data_ptr() + record.arena.numel()
+        for k, v in record.items():
+            if isinstance(v, torch.Tensor) and not (lo <= v.data_ptr() and v.data_ptr() + v.numel() * v.element_size() <= hi + 256):
+                raise ValueError(f"record tensor `{k}` lies outside the arena and would not be exchanged "
+                                 "(allocate it with env.alloc_rollout(..., log_prob=True / value=True))")
         self.record, self.group = record, group
         self.world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         self.nbytes = record.arena.numel()
@@ -270,7 +278,8 @@ def gather_trajectories(record: Dict[str, Optional[torch.Tensor]], group=None):
 
     Arena-backed records (`env.alloc_rollout`): zero-copy, returns views [world, T, B_local, ...] (see
     `TrajectoryExchange`; keep one exchange object alive to reuse its receive buffer across updates).
-    Plain dicts: packed once, gathered, returned as [T, world * B_local, ...] (legacy layout)."""
+    Plain dicts (legacy, one extra copy): packed, gathered, returned as [T, world * B_local, ...] — NOTE the different
+    layout (ranks concatenated on the env axis instead of a leading rank axis); prefer arena records."""
     if hasattr(record, "arena"):
         return TrajectoryExchange(record, group).gather()
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -343,10 +352,16 @@ class RolloutCollector:
             env.step_record(actions, buf, s)
 
     @torch.no_grad()
-    def collect(self) -> Dict[str, torch.Tensor]:
+    def collect(self, check: bool = True) -> Dict[str, torch.Tensor]:
+        """One batch of T steps.  `check` (default): read the engine's status word afterwards (`env.check_status()`, one
+        stream synchronisation) and raise if a launch of this batch lost an internal hand-off — its record must not reach
+        an update.  Pass check=False to keep the call asynchronous and call `env.check_status()` yourself before using
+        the data."""
         env, T, buf = self.env, self.T, self._buf
         if self.policy is None:
             env.rollout(T, out=buf, record=True)
+            if check:
+                env.check_status()
             return buf
         self._calls += 1
         if not self.use_graph or self._calls == 1:
@@ -359,7 +374,9 @@ class RolloutCollector:
                     self._policy_loop()            # recorded, not executed
                 self._graph = g
             self._graph.replay()
+        if check and not torch.cuda.is_current_stream_capturing():
+            env.check_status()
         out = buf if self._value is None or self._value is buf.get("value") else dict(buf)
         if self._value is not None:
-            out["value"] = self._value
-        return out
+            out["value"] = self._value         # (per-agent values live outside the arena: `out` is then a plain dict and
+        return out                             #  NOT exchangeable zero-copy — TrajectoryExchange refuses it)

@@ -149,6 +149,7 @@ class BatchedScotlandYardEnv:
                              int(bool(auto_reset)), int(waves_per_block), int(env_id_offset))
         self._handle = C.c_void_p()
         self._policy = None
+        self._checked_record = None
         _lib.check(self.lib.sy_env_create(C.byref(cfg), C.byref(self._handle)), "sy_env_create")
         wpb, blocks, lds = C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(self.lib.sy_env_launch_info(self._handle, C.byref(wpb), C.byref(blocks), C.byref(lds)))
@@ -349,7 +350,7 @@ class BatchedScotlandYardEnv:
         """The C ABI receives raw pointers: a buffer that is too short, of another dtype / device or not contiguous
         would be written past its end.  Every buffer must hold at least T rows of the engine's row shape."""
         B, A, NS = self.B, self.A, self.NS
-        RW = int(self.lib.sy_record_words(A))
+        RW = record_words(A)
         want = {"record": ((B, RW), torch.int32), "mask": ((B, A, NS), torch.uint8), "belief": ((B, NS), torch.float32),
                 "log_prob": ((B, A), torch.float32)}
         if not isinstance(out, dict) or out.get("record") is None:
@@ -381,7 +382,10 @@ class BatchedScotlandYardEnv:
             act = torch.as_tensor(actions).to(device=self.device, dtype=torch.int32).contiguous()
         if tuple(act.shape) != (self.B, self.A):
             raise ValueError(f"actions must have shape ({self.B}, {self.A})")
-        self._check_rollout_buffers(out, 1)
+        key = (id(out), out["record"].data_ptr() if isinstance(out, dict) and out.get("record") is not None else 0)
+        if self._checked_record != key:          # the same record row after row (a collector loop): validated once
+            self._check_rollout_buffers(out, 1)
+            self._checked_record = key
         if not 0 <= s < out["record"].shape[0]:
             raise IndexError("record row out of range")
         for k in ("mask", "belief"):
@@ -436,6 +440,10 @@ class BatchedScotlandYardEnv:
         rb = None
         if record:
             if self._policy is not None and isinstance(out, dict) and out.get("log_prob") is None:
+                if hasattr(out, "arena"):
+                    # a tensor bolted on outside the arena would silently miss the multi-GPU exchange, which ships the arena
+                    raise ValueError("this record was allocated without `log_prob` (alloc_rollout before set_policy?): "
+                                     "allocate it again after set_policy, or pass log_prob=True")
                 out["log_prob"] = torch.zeros((T, self.B, self.A), dtype=torch.float32, device=self.device)
             self._check_rollout_buffers(out, T, need_log_prob=self._policy is not None)
             rb = _lib.RolloutBuffers(*[out[k].data_ptr() if out.get(k) is not None else None

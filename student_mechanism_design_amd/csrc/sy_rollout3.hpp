@@ -568,7 +568,9 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
                     for (int i = 96; a + i < n16; i += 32) md[i] = mr[i];
                 }
             }
+#ifndef SY_DIAG_NO_ADVANCE     // timing-only build: every step overwrites step 0's rows (same instructions, no HBM stream)
             out.mask += mask_step;
+#endif
         }
         S3(3)
         // ---- evaluate half of the scan: masks of the new state, position-reward counts, next action
@@ -899,7 +901,9 @@ __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap
         if (rec_bel) {      // the belief before the step goes to the record
             SY_HOT(h_belrec);
             bl.record(out.belief, NS, live1);
+#ifndef SY_DIAG_NO_ADVANCE
             out.belief += bel_step;
+#endif
         }
         S3(0)
         // ---- what step s produced: entry s + 1 (the next observation, the reward, the outcome marks)
@@ -995,7 +999,9 @@ __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap
                 if (a < RW - 5 * A)
                     rdst[5 * A + a] = a == 0 ? t0_v : ((fl_v >> mw_shift) & mw_mask);
             }
+#ifndef SY_DIAG_NO_ADVANCE
             out.record += (size_t)B * RW;
+#endif
             if (POL && out.log_prob) {
                 if (store_ok && a < A) out.log_prob[(size_t)eh * A + a] = logp0_v;   // of the action executed in this step
                 out.log_prob += (size_t)B * A;
@@ -1044,8 +1050,14 @@ __global__ __launch_bounds__(1024, 4) void rollout3_kernel(const EngineParams p,
     }
     __syncthreads();
     if (e >= B) return;
+#if defined(SY_ISA_ROLE) && SY_ISA_ROLE == 1      // register census builds (tools/isa_only.sh -DSY_ISA_ROLE=1|2): one role alone
+    move_wave3<NR, REC, PT, POL, HS>(p, L, E, E1, lane, e, g, slot, T, out_arg);
+#elif defined(SY_ISA_ROLE) && SY_ISA_ROLE == 2
+    helper_wave3<NR, REC, PT, POL>(p, L, E, E1, lane, e, g, T, out_arg);
+#else
     if (helper_role) helper_wave3<NR, REC, PT, POL>(p, L, E, E1, lane, e, g, T, out_arg);
     else move_wave3<NR, REC, PT, POL, HS>(p, L, E, E1, lane, e, g, slot, T, out_arg);
+#endif
 }
 
 }  // namespace sy

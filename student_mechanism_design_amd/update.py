@@ -22,6 +22,29 @@ import torch
 from .policies import MappoPolicy
 
 
+class _OneHotLinear(torch.autograd.Function):
+    """y = oh @ Wt for a {0, 1} matrix oh [R, N] without gradient.  The weight gradient oh^T g is a product with a tiny
+    output (N x H) and a huge reduction dimension (R rows): the BLAS picks one workgroup column for it (0.81 ms at
+    R = 262 144 on MI355X); cutting R into chunks — a batched product followed by a sum, i.e. split-K — runs 3x faster."""
+
+    @staticmethod
+    def forward(ctx, oh, Wt):
+        ctx.save_for_backward(oh)
+        return oh @ Wt
+
+    @staticmethod
+    def backward(ctx, g):
+        (oh,) = ctx.saved_tensors
+        R, N = oh.shape
+        C = 1
+        while C < 64 and R % (2 * C) == 0 and R // (2 * C) >= 4096:
+            C *= 2
+        if C == 1:
+            return None, oh.t() @ g
+        gW = torch.bmm(oh.view(C, R // C, N).transpose(1, 2), g.reshape(C, R // C, g.shape[1])).sum(0)
+        return None, gW
+
+
 class MappoUpdater:
     def __init__(self, net: MappoPolicy, ell: torch.Tensor, env_graph: torch.Tensor, lr: float = 3e-4, clip: float = 0.2,
                  minibatch: int = 32768, value_coef: float = 0.5, use_graph: bool = False, mrx_money: int = 1000):
@@ -54,8 +77,9 @@ class MappoUpdater:
         # index_put with half a million colliding rows per minibatch (14 of round 2's 30 ms).
         oh_m = torch.zeros((mb, N), dtype=W1.dtype, device=pos.device).scatter_(1, mrx.unsqueeze(1), 1.0)
         oh_p = torch.zeros((mb, N), dtype=W1.dtype, device=pos.device).scatter_(1, pol, 1.0)
-        h0 = oh_m @ W1[0].t()                                                   # [mb, H]
-        hp = (oh_p @ W1[1:].reshape(P * H, N).t()).view(mb, P, H).transpose(0, 1)   # [P, mb, H]: all police actors in one matmul
+        lin = _OneHotLinear.apply
+        h0 = lin(oh_m, W1[0].t())                                               # [mb, H]
+        hp = lin(oh_p, W1[1:].reshape(P * H, N).t()).view(mb, P, H).transpose(0, 1)   # [P, mb, H]: all police actors in one matmul
         h = torch.relu(torch.cat([h0.unsqueeze(0), hp], 0) + b1.unsqueeze(1))   # [A, mb, H]
         logits = torch.baddbmm(b2.unsqueeze(1), h, W2.transpose(1, 2))          # [A, mb, N]
         # the affordable entries of every agent's ELL row: <= 16 per (row, agent)
@@ -75,7 +99,7 @@ class MappoUpdater:
         actor_loss = -surr.mean()                                               # mappo_agent.py:284-291
         # CentralCritic on [mrx] + [police] * P (mappo_agent.py:32-44): the P copies of the police block share one input
         c1 = net.critic[0].weight.view(H, A, N)
-        hc = torch.relu(oh_m @ c1[:, 0].t() + oh_p @ c1[:, 1:].sum(1).t() + net.critic[0].bias)
+        hc = torch.relu(lin(oh_m, c1[:, 0].t()) + lin(oh_p, c1[:, 1:].sum(1).t()) + net.critic[0].bias)
         value = net.critic[2](hc).squeeze(-1)
         critic_loss = torch.nn.functional.mse_loss(value, team_ret)             # :260-265
         return actor_loss, critic_loss

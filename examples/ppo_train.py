@@ -3,9 +3,11 @@
 
   collect   T fused env-steps of B envs with the CURRENT actors sampling inside the rollout kernel
             (env.set_policy -> sy_env_set_policy; log-probs recorded by the kernel)
-  returns   discounted returns per agent, advantages standardised as in MappoAgent.ppo_update
-  update    critic MSE + clipped surrogate over minibatches of the recorded (observation, action) pairs
-            (torch autograd on the same MappoPolicy module), then DeviceMappoPolicy.refresh()
+  returns   discounted returns per agent in one launch (sy_returns_advantages), advantages standardised as in
+            MappoAgent.ppo_update
+  update    update.MappoUpdater: critic MSE + clipped surrogate over minibatches of the recorded (observation, action)
+            pairs (torch autograd on the same MappoPolicy module, no host sync, each step one HIP graph), then
+            DeviceMappoPolicy.refresh()
 
 Everything stays in HBM; the only host work is the Python loop.  Needs an MI355X and the built engine.
 
@@ -22,7 +24,8 @@ sys.path.insert(0, '.')
 import student_mechanism_design_amd as sy  # noqa: E402
 from student_mechanism_design_amd import collector as col  # noqa: E402
 from student_mechanism_design_amd.metrics import rollout_metrics  # noqa: E402
-from student_mechanism_design_amd.policies import DeviceMappoPolicy, MappoPolicy, ppo_loss  # noqa: E402
+from student_mechanism_design_amd.policies import DeviceMappoPolicy, MappoPolicy  # noqa: E402
+from student_mechanism_design_amd.update import MappoUpdater  # noqa: E402
 
 
 def main():
@@ -45,7 +48,7 @@ def main():
     net = MappoPolicy(N, P, hidden_size=64).to(dev)
     fused = DeviceMappoPolicy(net, seed=0)
     env.set_policy(fused)
-    opt = torch.optim.Adam(net.parameters(), lr=args.lr)
+    up = MappoUpdater(net, env.ell, env.env_graph, lr=args.lr, minibatch=args.minibatch, use_graph=True)
     out = env.alloc_rollout(T)
     t_collect = t_update = 0.0
     for it in range(args.iters):
@@ -54,43 +57,21 @@ def main():
         rec = env.rollout(T, out=out)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        m = rollout_metrics(rec, N)
-        done = (rec["terminated"] | rec["truncated"]).bool()
-        reward = rec["reward"].float()                                            # [T, B, A]
-        ret = col.discounted_returns(reward, done, args.gamma)                     # mappo_agent.py:247-254
-        pos = rec["pos"].reshape(T * B, A)
-        act = rec["action"].reshape(T * B, A).long()
-        mask = rec["mask"][..., :N].reshape(T * B, A, N).bool()
-        old_lp = rec["log_prob"].reshape(T * B, A)
-        ret_f = ret.reshape(T * B, A)
-        valid = (act >= 0).float()
-        perm = torch.randperm(T * B, device=dev)
-        la = lc = 0.0
-        nb = 0
-        for i in range(0, T * B, args.minibatch):
-            idx = perm[i:i + args.minibatch]
-            obs = {"MrX_pos": pos[idx, 0], "Polices_pos": pos[idx, 1:]}
-            value = net.value(obs)                                                 # [mb]
-            team_ret = ret_f[idx].sum(-1)
-            adv = col.standardized_advantages(ret_f[idx], value.detach().unsqueeze(-1))
-            pm = net.probs(obs) * mask[idx].float()
-            pm = pm / (pm.sum(-1, keepdim=True) + 1e-8)
-            new_lp = torch.log(torch.gather(pm, -1, act[idx].clamp_min(0).unsqueeze(-1)).squeeze(-1) + 1e-8)
-            al, cl = ppo_loss(new_lp * valid[idx], old_lp[idx] * valid[idx], adv, value, team_ret)
-            opt.zero_grad()
-            (al + 0.5 * cl).backward()
-            opt.step()
-            la += float(al.detach())
-            lc += float(cl.detach())
-            nb += 1
-        fused.refresh()                                                            # the kernel sees the new weights
+        # returns as ONE launch on the packed record (mappo_agent.py:247-254), then a sync-free minibatch pass
+        # (critic MSE + clipped surrogate, :256-293) and the refresh of the weights the kernel reads
+        ret, _ = col.device_returns(rec["reward"], rec["terminated"], args.gamma, done_b=rec["truncated"])
+        al, cl = up.update(rec, ret)
+        fused.refresh()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
         t_collect += t1 - t0
         t_update += t2 - t1
+        env.check_status()
+        m = rollout_metrics(rec, N)                                                # (reporting only: host reads below)
+        reward = rec["reward"]
         print(f"iter {it:3d}  episodes {int(m['num_episodes']):6d}  MrX win rate {float(m['win_rate']):.3f}  "
               f"mean length {float(m['mean_episode_length']):5.1f}  mean reward MrX {float(reward[..., 0].mean()):+.3f} "
-              f"police {float(reward[..., 1:].mean()):+.3f}  actor loss {la / nb:+.4f}  critic loss {lc / nb:.3f}")
+              f"police {float(reward[..., 1:].mean()):+.3f}  actor loss {float(al):+.4f}  critic loss {float(cl):.3f}")
     n = args.iters * T * B * A
     print(f"collect: {n / t_collect / 1e9:.2f} G agent-steps/s ({t_collect / args.iters * 1e3:.1f} ms per rollout); "
           f"update: {t_update / args.iters * 1e3:.1f} ms per iteration")

@@ -7,7 +7,7 @@ cd $GRAFT_REPO_ROOT && export TMPDIR=/tmp
 TAG=${1:-r03_final}
 O=gpurun_out/$TAG; rm -rf $O; mkdir -p $O/publish
 P=$O/publish
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu --no-verify --no-config3 --steps 20 --warmup 5 --repeats 10 > $O/stats.log 2>&1 || { tail -5 $O/stats.log; exit 1; }
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 bench.py --no-cpu --no-verify --no-config3 --steps 20 --warmup 5 > $O/stats.log 2>&1 || { tail -5 $O/stats.log; exit 1; }
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -- python3 bench.py --no-cpu --no-verify --no-config3 --steps 3 --warmup 1 --repeats 1 > $O/fetch.log 2>&1 || { tail -5 $O/fetch.log; exit 1; }
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -- python3 bench.py --no-cpu --no-verify --no-config3 --steps 3 --warmup 1 --repeats 1 > $O/write.log 2>&1 || { tail -5 $O/write.log; exit 1; }
 bash tools/collect_pmc.sh tools/pmc_sq.txt ${TAG}_sq --no-config3 || exit 1

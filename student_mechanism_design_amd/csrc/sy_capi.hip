@@ -176,6 +176,7 @@ int sy_env_set_policy(sy_env* env, const sy_mappo_weights* w, int32_t hidden) {
         env->p.pbound = nullptr;
         env->p.pH = 0;
         env->p.pslice = 0;
+        env->p.pcap = 0;
         return SY_OK;
     }
     if (!w->w1t || !w->b1 || !w->w2 || !w->b2) return fail(SY_ERR_INVALID, "sy_env_set_policy: w1t, b1, w2, b2 are required%s");
@@ -199,6 +200,7 @@ int sy_env_set_policy(sy_env* env, const sy_mappo_weights* w, int32_t hidden) {
     env->p.pw1t = w->w1t; env->p.pb1 = w->b1; env->p.pw2 = w->w2; env->p.pb2 = w->b2;
     env->p.pbound = w->logit_bound;
     env->p.pslice = pslice;
+    env->p.pcap = pl.pcap;
     env->p.pH = hidden;
     return SY_OK;
 }

@@ -7,9 +7,11 @@
 
 namespace sy {
 
-int rollout_policy_slice(int family, int A, int hidden) {
-    // rollout3: A hidden vectors + 8 slots of 16 B; rollout2: the fixed round-1 slice (8 vectors of 64 floats + slots)
-    return family == 3 ? A * hidden * 4 + 128 : SY_POLICY_SLICE;
+int rollout_policy_slice(int family, int A, int hidden, int entry_cap) {
+    // rollout3: A hidden vectors + 8 slots of 16 B + the episode's share of the pair's compacted entry list (node | agent
+    // | half in 2 bytes, the logit in 4: 6 bytes per affordable ELL entry, at most `entry_cap` per episode);
+    // rollout2: the fixed round-1 slice (8 vectors of 64 floats + slots)
+    return family == 3 ? A * hidden * 4 + 128 + ((6 * entry_cap + 15) & ~15) + 16 : SY_POLICY_SLICE;
 }
 
 RolloutPlan plan_rollout(const EngineParams& p, bool record, int wpb, size_t lds_base, int policy_hidden) {
@@ -23,6 +25,7 @@ RolloutPlan plan_rollout(const EngineParams& p, bool record, int wpb, size_t lds
     const int H = policy_hidden > 0 ? policy_hidden : p.pH;
     pl.pol = pol;
     pl.pslice = 0;
+    pl.pcap = 0;
     const bool paired = (wpb & 1) == 0;              // paired move waves need an even number of episodes per block
     const int per_pass = 64 / p.scan_w;              // agents one pass of the paired scan covers
     const bool has_belief = p.st.belief != nullptr;
@@ -92,7 +95,12 @@ RolloutPlan plan_rollout(const EngineParams& p, bool record, int wpb, size_t lds
         pl.pol = false;      // no policy instance (odd block sizes; boards of more than 256 nodes whose agents need two scan
                              // passes): sy_env_set_policy / sy_env_rollout refuse these configurations
     }
-    if (pl.pol) pl.pslice = rollout_policy_slice(pl.family, p.A, H);
+    if (pl.pol) {
+        // affordable entries an episode can have: every agent's row, as wide as the scan covers
+        const int cols = pl.hs > 0 ? pl.hs * half_scan_gw(p.P) : SY_ELL_WIDTH;
+        pl.pcap = p.A * (cols < SY_ELL_WIDTH ? cols : SY_ELL_WIDTH);
+        pl.pslice = rollout_policy_slice(pl.family, p.A, H, pl.pcap);
+    }
     pl.threads = pl.family == 3 ? threads3 : threads12;
     pl.lds = lds_base + (size_t)wpb * pl.pslice;
     return pl;

@@ -39,7 +39,9 @@ struct EngineParams {
     const float* pw2;             // [A][N][H]
     const float* pb2;             // [A][N]
     int32_t pH;
-    int32_t pslice;               // per-episode LDS scratch of the pipeline's policy path: A * H * 4 + 128 bytes
+    int32_t pslice;               // per-episode LDS scratch of the pipeline's policy path: A * H * 4 + 128 bytes + its share of the
+                                  // pair's entry list (sy_dispatch.hip::rollout_policy_slice)
+    int32_t pcap;                 // affordable ELL entries an episode can have (sizes the pair's entry list of the policy path)
     const float* pbound;          // [A] upper bound of any logit of actor a (the underflow rule's cheap test); may be null
     uint32_t* status;             // device status word (sy_env_bind_status); nullptr = failures are not reported
 };
@@ -60,12 +62,13 @@ struct RolloutPlan {
     int threads;       // block size
     size_t lds;        // dynamic LDS bytes of the launch (board + episode slices + policy scratch)
     int pslice;        // per-episode LDS scratch of the in-kernel policy on this family (0 without a policy)
+    int pcap;          // ... of which the entry list holds this many entries per episode
 };
 // `policy_hidden` > 0 asks for the plan WITH a policy of that hidden size even if none is set yet (sy_env_set_policy
 // validates its argument against the instance that would run); 0 = use p.pw2 / p.pH as they are.
 RolloutPlan plan_rollout(const EngineParams& p, bool record, int wpb, size_t lds_base, int policy_hidden = 0);
 void rollout_plan_name(const RolloutPlan& pl, char* buf, size_t n);     // e.g. "sy::rollout3_kernel<4,true,4,false,2>"
-int rollout_policy_slice(int family, int A, int hidden);
+int rollout_policy_slice(int family, int A, int hidden, int entry_cap);
 
 hipError_t launch_rollout(const EngineParams& p, int T, const sy_rollout_buffers& out, int blocks, int wpb, size_t lds,
                           hipStream_t stream);

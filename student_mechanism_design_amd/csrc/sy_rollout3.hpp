@@ -1,6 +1,8 @@
 // sy_rollout3.hpp — rollout3_kernel, the move / helper pipeline (the default fused rollout).  Instantiated per
 // instance group by sy_rollout3_*.hip so that an edit here rebuilds in parallel.
 #pragma once
+#include <type_traits>
+
 #include "sy_pair.hpp"
 
 namespace sy {
@@ -55,6 +57,9 @@ static constexpr int kFlagTerm = 1, kFlagWinShift = 2, kFlagRestart = 16, kFlagR
 // NC is the launch's choice (the pool's widest row fits NC * GW).  Counts, the r-th legal neighbour in ascending node
 // order (all columns ranked in one NC*GW-bit field) and the position-reward count are the quantities of scan_sample;
 // results reach the agent lanes through the LDS slots of the paired scan.
+#ifndef SY_COOP_BATCH
+#define SY_COOP_BATCH 3      // rounds (of 8 entries) whose row pieces are in flight together (hidden 33..64: two 16-byte pieces per lane and round)
+#endif
 template <int GW, int NC>
 struct HalfScan {
     static_assert(GW * NC <= 32, "one rank field per agent");
@@ -66,6 +71,7 @@ struct HalfScan {
     struct In { uint32_t ent[NC]; uint32_t xa; int ma, mq; };
     struct Pol {                 // learned policy (sy_env_set_policy): my group's actor and its LDS scratch, my episode
         uint32_t hs, sl, slr;
+        uint32_t pol0, dpol, list, logits;   // the pair's scratch: episode 0's base, distance to episode 1's, entry descriptors, entry logits
         const float* w2a;
         const float* b2a;
         float thr;               // log(1e-8) + log(N) + bound[agent]   (+inf without a bound: never the exact path)
@@ -146,8 +152,12 @@ struct HalfScan {
     }
 
     // ---- the learned policy choosing the action (scan_eval_pair_policy3 in the half-wave layout) ----
-    __device__ __forceinline__ Pol make_pol(const EngineParams& p, int lane, int A, uint32_t pol0, uint32_t pol1) const {
+    __device__ __forceinline__ Pol make_pol(const EngineParams& p, int lane, int A, uint32_t pol0, uint32_t pol1, uint32_t plist) const {
         Pol q;
+        q.pol0 = pol0;
+        q.dpol = pol1 - pol0;
+        q.list = plist;
+        q.logits = plist + (uint32_t)((4 * p.pcap + 15) & ~15);      // behind the 2-byte descriptors of both episodes
         const int H = p.pH;
         const uint32_t pb = lane >= 32 ? pol1 : pol0;
         const uint32_t slots = (uint32_t)(A * H) * 4u;
@@ -210,17 +220,73 @@ struct HalfScan {
             *lds_at<uint8_t>(n) = 1;
             prev[k] = n;
         }
-        // logits of the affordable entries: the first column of every lane, further columns only on the steps where
-        // some agent of the pair stands on a row that wide (wave-uniform)
-#ifndef SY_POL_BATCH_HALF
-#define SY_POL_BATCH_HALF 4
-#endif
+        // ---- logits of the affordable entries, COOPERATIVELY.  Round 2 gave every scan lane its own 64-term dot product:
+        // 16 requests of 16 bytes per lane from up to 64 different rows, four dependent L2 round trips per column.  Here
+        // the entries of the pair are compacted into a list (2 bytes each: node | agent << 8 | half << 11) and every group
+        // of 8 lanes takes one entry per round: its lanes read the entry's w2 row as 16-byte pieces (piece j, j + 8, ...:
+        // whole rows, eight per instruction), FMAs against the agent's hidden vector in LDS, a DPP sum over the 8 lanes;
+        // the loads of a few rounds are in flight together, so ~40 entries cost two round trips, not four to eight.
         float l[NC];
-        l[0] = logit_of<SY_POL_BATCH_HALF>(pl, nb[0], H);
+        {
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            uint32_t eidx[NC];
+            float bias[NC];                                                    // b2 of my entries: requested now, needed after the rounds
 #pragma unroll
-        for (int k = 1; k < NC; ++k) {
-            l[k] = 0.0f;
-            if (bo[k] != 0ull) l[k] = logit_of<SY_POL_BATCH_HALF>(pl, nb[k], H);
+            for (int k = 0; k < NC; ++k) bias[k] = pl.b2a[nb[k]];
+            uint32_t ne = 0;                                                   // wave-uniform
+#pragma unroll
+            for (int k = 0; k < NC; ++k) {
+                eidx[k] = ne + __builtin_amdgcn_mbcnt_hi((uint32_t)(bo[k] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bo[k], 0u));
+                ne += (uint32_t)__popcll(bo[k]);
+                if (lanes(bo[k])) *lds_at<uint16_t>(pl.list + 2u * eidx[k]) = (uint16_t)(nb[k] | ((uint32_t)ag << 8) | ((uint32_t)(lane & 32) << 6));
+            }
+            wave_lds_fence();
+            const uint32_t q = (uint32_t)lane >> 3, j = (uint32_t)lane & 7u;   // 8 lanes per entry, 8 entries per round
+            const uint32_t nq = (uint32_t)H >> 2;                              // 16-byte pieces per row (<= 32): lane j takes j, j + 8, ...
+            auto rounds = [&](auto pieces, auto batch) {
+                constexpr int PPL = decltype(pieces)::value;                   // pieces per lane
+                constexpr int RB = decltype(batch)::value;                     // rounds whose loads are in flight together
+                for (uint32_t r0 = 0; 8u * r0 < ne; r0 += RB) {
+                    f4 w[RB][PPL];
+                    uint32_t hsa[RB];
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) {
+                        const uint32_t e = 8u * (r0 + (uint32_t)u) + q;
+                        const uint32_t d = e < ne ? (uint32_t)*lds_at<uint16_t>(pl.list + 2u * e) : 0u;
+                        const uint32_t node = d & 255u, agu = (d >> 8) & 7u;
+                        hsa[u] = pl.pol0 + (d >> 11) * pl.dpol + (agu * (uint32_t)H + 4u * j) * 4u;
+                        const float* rp = w2_all + ((size_t)(agu * (uint32_t)N + node) * H + 4u * j);
+#pragma unroll
+                        for (int m = 0; m < PPL; ++m)
+                            w[u][m] = (j + 8u * m < nq) ? *reinterpret_cast<const f4*>(rp + 32 * m) : (f4){0.0f, 0.0f, 0.0f, 0.0f};
+                    }
+#pragma unroll
+                    for (int u = 0; u < RB; ++u) {
+                        const uint32_t e = 8u * (r0 + (uint32_t)u) + q;
+                        float part = 0.0f;
+#pragma unroll
+                        for (int m = 0; m < PPL; ++m) {
+                            if (j + 8u * m < nq) {
+                                const f4 h = *lds_at<f4>(hsa[u] + 128u * m);
+                                part = fmaf(w[u][m].x, h.x, part); part = fmaf(w[u][m].y, h.y, part);
+                                part = fmaf(w[u][m].z, h.z, part); part = fmaf(w[u][m].w, h.w, part);
+                            }
+                        }
+                        part += dpp_mov<0xB1>(part);                          // my 8 lanes: the quad (lane ^ 1, lane ^ 2), then the other quad
+                        part += dpp_mov<0x4E>(part);
+                        part += dpp_mov<0x141>(part);                         // row_half_mirror: lane i <-> 7 - i
+                        if (j == 0u && e < ne) *lds_at<float>(pl.logits + 4u * e) = part;
+                    }
+                }
+            };
+            const uint32_t ppl = (nq + 7u) >> 3;
+            if (ppl <= 1u) rounds(std::integral_constant<int, 1>{}, std::integral_constant<int, 4>{});
+            else if (ppl == 2u) rounds(std::integral_constant<int, 2>{}, std::integral_constant<int, SY_COOP_BATCH>{});
+            else if (ppl == 3u) rounds(std::integral_constant<int, 3>{}, std::integral_constant<int, 2>{});
+            else rounds(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{});
+            wave_lds_fence();
+#pragma unroll
+            for (int k = 0; k < NC; ++k) l[k] = lanes(bo[k]) ? *lds_at<float>(pl.logits + 4u * eidx[k]) + bias[k] : 0.0f;
         }
 #pragma unroll
         for (int k = 0; k < NC; ++k)
@@ -329,7 +395,9 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         for (int i = a0; i < NS; i += 32) vis32[i] = p.st.visits[(size_t)eh * NS + i];
     // in-kernel policy: per-episode scratch behind the episode slices
     const uint32_t pol0 = lds_off(L.env_base) + (uint32_t)p.wpb * (uint32_t)p.wave_lds_bytes + (uint32_t)slot * (uint32_t)p.pslice;
-    const uint32_t pol1 = pol0 + (uint32_t)p.pslice;
+    // (the pair's scratch = two episode slices: [vectors + slots of episode 0][... of episode 1][the pair's entry list])
+    const uint32_t pol1 = pol0 + (uint32_t)(A * p.pH) * 4u + 128u;
+    const uint32_t plist = pol1 + (uint32_t)(A * p.pH) * 4u + 128u;
     PolLane3 pll;
     float logp_v = 0.0f;
     if (POL) pll = make_pol_lane3(p, sm, lane, A, pol0, pol1);
@@ -358,7 +426,7 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
     if (!one_pass) psl2 = make_pair_scan_lane(E, E1, sm, lane, A, NS, sm.per_pass);
     int act_v = -1, cost_v = 0, qcnt = 0;
     typename HalfScan<GWH, (HALF ? HS : 1)>::Pol hpl;
-    if (HALF && POL) hpl = hs.make_pol(p, lane, A, pol0, pol1);
+    if (HALF && POL) hpl = hs.make_pol(p, lane, A, pol0, pol1, plist);
     if (HALF) {
         const auto g0 = hs.gather(pos_v, mon_v, xw[0]);
         if (POL) {

@@ -489,6 +489,14 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
     const uint32_t POL32 = (uint32_t)POLM;                                       // ... of one half
 
 
+#ifdef SY_ENDTIMES3
+    const unsigned long long et_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+#ifndef SY_NO_PRIO_TURNS
+    const int pslot = slot ^ 8;                                   // the move wave that shares my SIMD: wave w ^ 4 = pair slot ^ 8
+    const bool partner_ok = pslot < p.wpb && (int)(blockIdx.x * p.wpb) + pslot < B;
+    const int* partner_sync = reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(E.sync) + (ptrdiff_t)(pslot - slot) * p.wave_lds_bytes);
+#endif
     S3_DECL
     for (int s = 0; s < T; ++s) {
         int ln = lane;                               // laundered: lane predicates are recomputed every step
@@ -497,6 +505,18 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         const int a = ln & 31;
         const bool is_pol = a >= 1 && a <= P;
         S3(7)
+#ifndef SY_NO_PRIO_TURNS
+        // The two move waves that share a SIMD (waves w and w ^ 4 of the block) level each other: every 8 steps a wave looks
+        // at its partner's published entry counter and takes the HIGHER issue priority if it is behind (ties: turns).  Left
+        // alone the arbiter serves the older wave first — tools/endtimes.py: waves 0-3 of every block finished a launch at
+        // 390 us, waves 4-7 at 450 us, and a launch takes as long as the starved half.  Levelled, both finish at 440 us and
+        // the spread of all wave run times falls from 32 to 12 us: a launch ends 6-7 % earlier.  Helpers stay at priority 0.
+        if ((s & 7) == 0) {
+            const int other = partner_ok ? lds_peek(partner_sync) : s;
+            const bool ahead = s > other || (s == other && ((((unsigned)s >> 3) ^ ((unsigned)slot >> 3)) & 1u) != 0u);
+            if (ahead) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+        }
+#endif
 
         // ---- moves (yard.py:161-243), both episodes at once
         const int tgt_v = act_v >= 0 ? act_v : pos_v;
@@ -678,6 +698,14 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         S3(5)
     }
     S3_DUMP("move  [moves+outcome, restart, rng+gather, visits+apsp+maskcopy, eval, publish, rewards, loophead]", T)
+#ifdef SY_ENDTIMES3    // load-balance builds (tools/endtimes.py): this wave's start / end on the constant 100 MHz clock, left in the
+                       // padding bytes [N, NS) of the last recorded mask row of the episode's last agent
+    if (REC && out.mask && (lane & 31) == 0 && store_ok && NS - N >= 8) {
+        uint32_t* tw = reinterpret_cast<uint32_t*>(out.mask - mask_step + (size_t)eh * A * NS + (size_t)(A - 1) * NS + N);
+        tw[0] = (uint32_t)et_t0;
+        tw[1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+    }
+#endif
 
     // ---- write the live state back; state pointers re-read from the kernel arguments
     const KernargParams kq = kernarg_params();

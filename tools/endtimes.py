@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Launch-level load balance of the fused rollout: per move wave start / end times.
 
-Needs an engine built with -DSY_ENDTIMES (the kernel leaves both times, 100 MHz ticks, in the padding
-words of the last record row):
+Needs an engine built with -DSY_ENDTIMES3 (the pipeline's move waves leave both times, 100 MHz ticks, in the padding
+bytes of the last recorded mask row; --rollout2: -DSY_ENDTIMES, padding words of the last record row):
     SY_HIPCC_FLAGS=-DSY_ENDTIMES python -m student_mechanism_design_amd.build   # or build to another path
     SY_ENGINE_LIB=<that .so> python tools/endtimes.py [T]
 """
@@ -14,7 +14,7 @@ import torch
 sys.path.insert(0, '.')
 import student_mechanism_design_amd as sy  # noqa: E402
 
-T = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+T = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 256
 boards = sy.sample_board_pool(8, 200, 400, seed=0)
 env = sy.BatchedScotlandYardEnv(4096, boards, 4, 20, np.full(11, 0.5), seed=1234, reveal_interval=5)
 env.reset(seed=1)
@@ -23,8 +23,12 @@ W = env.waves_per_block
 for it in range(3):
     env.rollout(T, out=out)
     torch.cuda.synchronize()
-    rec = out["record"][T - 1].cpu().numpy().astype(np.int64) & 0xffffffff   # [B, RW]
-    st, en = rec[:, -2], rec[:, -1]
+    if "--rollout2" in sys.argv:       # round 1's kernel (-DSY_ENDTIMES -DSY_NO_PIPELINE): padding words of the last record row
+        rec = out["record"][T - 1].cpu().numpy().astype(np.int64) & 0xffffffff   # [B, RW]
+        st, en = rec[:, -2], rec[:, -1]
+    else:                              # the pipeline (-DSY_ENDTIMES3): padding bytes of the last mask row of the last agent
+        pad = out["mask"][T - 1, :, -1, 200:208].contiguous().cpu().numpy().view(np.uint32).astype(np.int64)   # [B, 2]
+        st, en = pad[:, 0], pad[:, 1]
     t0 = st.min()
     run = (en - st) / 100.0
     end = (en - t0) / 100.0

@@ -510,11 +510,12 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         // at its partner's published entry counter and takes the HIGHER issue priority if it is behind (ties: turns).  Left
         // alone the arbiter serves the older wave first — tools/endtimes.py: waves 0-3 of every block finished a launch at
         // 390 us, waves 4-7 at 450 us, and a launch takes as long as the starved half.  Levelled, both finish at 440 us and
-        // the spread of all wave run times falls from 32 to 12 us: a launch ends 6-7 % earlier.  Helpers stay at priority 0.
+        // the spread of all wave run times falls from 32 to 12 us: a launch ends 6-7 % earlier.  Move waves use priorities 3 / 2,
+        // the helpers level each other the same way one class below (1 / 0: another 0.5 %).
         if ((s & 7) == 0) {
             const int other = partner_ok ? lds_peek(partner_sync) : s;
             const bool ahead = s > other || (s == other && ((((unsigned)s >> 3) ^ ((unsigned)slot >> 3)) & 1u) != 0u);
-            if (ahead) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(2);
+            if (ahead) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(3);
         }
 #endif
 
@@ -984,6 +985,15 @@ __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap
         const bool upper = ln >= 32;
         const int a = ln & 31;
         S3(7)
+#ifndef SY_NO_PRIO_TURNS   // the helper that is behind its SIMD partner helper goes first (priorities 1 / 0, below the move waves)
+        if ((s & 7) == 0) {
+            const int hslot = e - (int)(blockIdx.x * p.wpb);
+            const int ps = hslot ^ 8;
+            const bool ok = ps < p.wpb && (int)(blockIdx.x * p.wpb) + ps < B;
+            const int other = ok ? lds_peek(reinterpret_cast<const int*>(reinterpret_cast<const unsigned char*>(E.sync + 1) + (ptrdiff_t)(ps - hslot) * p.wave_lds_bytes)) : s;
+            if (s > other || (s == other && (hslot & 8))) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(1);
+        }
+#endif
 #ifdef SY_DIAG_H_IDLE     // timing-only build: the helper just consumes the entries (the move wave's chain alone)
         {
             wait_entry(s + 1);

@@ -491,6 +491,7 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
 
 #ifdef SY_ENDTIMES3
     const unsigned long long et_t0 = __builtin_amdgcn_s_memrealtime();
+    uint32_t et_restarts = 0, et_conflicts = 0;
 #endif
 #ifndef SY_NO_PRIO_TURNS
     const int pslot = slot ^ 8;                                   // the move wave that shares my SIMD: wave w ^ 4 = pair slot ^ 8
@@ -535,6 +536,9 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         if (4 < P) CF |= pair_conflicts<4>(tgt_v, pos_v) & (POLM & (POLM << 4));
         if (5 < P) CF |= pair_conflicts<5>(tgt_v, pos_v) & (POLM & (POLM << 5));
         if (6 < P) CF |= pair_conflicts<6>(tgt_v, pos_v) & (POLM & (POLM << 6));
+#ifdef SY_ENDTIMES3
+        et_conflicts += CF != 0ull ? 1u : 0u;
+#endif
         if (CF == 0ull) {                              // no police collision in either episode: order cannot matter
             SY_HOT(m_moves);
             const uint64_t mv = POLM & ~SK & bal(tgt_v != pos_v);
@@ -568,6 +572,9 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         // evaluated): by the time the shortest-path gathers read them back, the write is long done
         if (!POL && lanes(kAgentSlots)) lds_at<int>(xch_off)[a] = pos_m;
         const int t_rew = t_v;             // pre-increment timestep of this step (reward_calculator.py:145,219)
+#ifdef SY_ENDTIMES3
+        et_restarts += NEED != 0ull ? 1u : 0u;
+#endif
         if (NEED != 0ull) {
             const int st = sample_starts_pair(NEED, ln, a, A, N, gid, sc_v + 1u, p.seed_lo, p.seed_hi);
             const int m_init = a == 0 ? SY_MRX_MONEY : (a < A ? p.money0 : 0);     // yard.py:117-119
@@ -705,6 +712,9 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         uint32_t* tw = reinterpret_cast<uint32_t*>(out.mask - mask_step + (size_t)eh * A * NS + (size_t)(A - 1) * NS + N);
         tw[0] = (uint32_t)et_t0;
         tw[1] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+        uint32_t* tc = reinterpret_cast<uint32_t*>(out.mask - mask_step + (size_t)eh * A * NS + (size_t)(A - 2) * NS + N);
+        tc[0] = et_restarts;      // steps of this wave on which an episode of the pair restarted
+        tc[1] = et_conflicts;     // steps on which the police moves took the exact sequential order
     }
 #endif
 

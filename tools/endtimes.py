@@ -29,6 +29,19 @@ for it in range(3):
     else:                              # the pipeline (-DSY_ENDTIMES3): padding bytes of the last mask row of the last agent
         pad = out["mask"][T - 1, :, -1, 200:208].contiguous().cpu().numpy().view(np.uint32).astype(np.int64)   # [B, 2]
         st, en = pad[:, 0], pad[:, 1]
+        cnt = out["mask"][T - 1, :, -2, 200:208].contiguous().cpu().numpy().view(np.uint32).astype(np.int64)   # [B, 2] restarts, conflicts
+        if it == 2:
+            w = slice(0, None, 2)          # one entry per move wave (both halves carry the same numbers)
+            r = (en - st)[w] / 100.0
+            X = np.stack([np.ones_like(r), cnt[w, 0], cnt[w, 1]], 1).astype(np.float64)
+            coef, *_ = np.linalg.lstsq(X, r, rcond=None)
+            res = r - X @ coef
+            print(f"    per wave: restart steps mean {cnt[w,0].mean():.1f} sd {cnt[w,0].std():.1f}, conflict steps mean {cnt[w,1].mean():.1f} sd {cnt[w,1].std():.1f}")
+            print(f"    run time = {coef[0]:.1f} us + {coef[1]*1e3:.0f} ns per restart step + {coef[2]*1e3:.0f} ns per conflict step; residual sd {res.std():.1f} us (of {r.std():.1f})")
+            board = np.arange(r.shape[0]) // (r.shape[0] // 8)
+            print("    mean run by board:", np.array([r[board == g].mean() for g in range(8)]).round(1))
+            xcd = (np.arange(r.shape[0]) // 8) % 8
+            print("    mean run by block % 8 (XCD):", np.array([r[xcd == g].mean() for g in range(8)]).round(1))
     t0 = st.min()
     run = (en - st) / 100.0
     end = (en - t0) / 100.0

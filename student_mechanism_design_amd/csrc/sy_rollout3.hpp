@@ -529,13 +529,15 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
             const uint64_t mrx_moves = (uint64_t)z31(hit_lo) | ((uint64_t)z31(hit_hi) << 32);   // lanes 0 / 32
             pos_v = lanes(mrx_moves) ? tgt_v : pos_v;
         }
-        uint64_t CF = 0;   // any police pair that could interact this step?
-        if (1 < P) CF |= pair_conflicts<1>(tgt_v, pos_v) & (POLM & (POLM << 1));
-        if (2 < P) CF |= pair_conflicts<2>(tgt_v, pos_v) & (POLM & (POLM << 2));
-        if (3 < P) CF |= pair_conflicts<3>(tgt_v, pos_v) & (POLM & (POLM << 3));
-        if (4 < P) CF |= pair_conflicts<4>(tgt_v, pos_v) & (POLM & (POLM << 4));
-        if (5 < P) CF |= pair_conflicts<5>(tgt_v, pos_v) & (POLM & (POLM << 5));
-        if (6 < P) CF |= pair_conflicts<6>(tgt_v, pos_v) & (POLM & (POLM << 6));
+        uint64_t CF = 0;   // any police pair that could interact this step?  INV: the officers of those pairs (both indices)
+#ifdef SY_CONFLICT_ALL
+#define SY_PAIR(D) if (D < P) CF |= pair_conflicts<D>(tgt_v, pos_v) & (POLM & (POLM << D));
+#else
+        uint64_t INV = 0;
+#define SY_PAIR(D) if (D < P) { const uint64_t c = pair_conflicts<D>(tgt_v, pos_v) & (POLM & (POLM << D)); CF |= c; INV |= c | (c >> D); }
+#endif
+        SY_PAIR(1) SY_PAIR(2) SY_PAIR(3) SY_PAIR(4) SY_PAIR(5) SY_PAIR(6)
+#undef SY_PAIR
 #ifdef SY_ENDTIMES3
         et_conflicts += CF != 0ull ? 1u : 0u;
 #endif
@@ -546,7 +548,23 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
             mon_v -= lanes(mv) ? cost_v : 0;                                  // :234-236
         } else {                                      // exact sequential order (:191-243), harmless for a clean half
             const bool skip_v = lanes(SK);
+#ifndef SY_CONFLICT_ALL
+            // A third of the steps get here (tools/endtimes.py: the random policy keeps officers next to each other, and
+            // a target that is another officer's node or target is an interaction).  Officers outside every flagged pair
+            // share no node with anybody: they move as on the fast path, all at once; only the officers of flagged pairs —
+            // usually two — take the sequential loop, in index order (an officer that already moved finds its own node
+            // occupied and stays: the loop body is idempotent for it).
+            {
+                const uint64_t mv = POLM & ~SK & ~INV & bal(tgt_v != pos_v);
+                pos_v = lanes(mv) ? tgt_v : pos_v;
+                mon_v -= lanes(mv) ? cost_v : 0;
+            }
+            const uint32_t inv_any = (uint32_t)INV | (uint32_t)(INV >> 32);      // involved in either episode of the pair
+#endif
             for (int k = 1; k <= P; ++k) {
+#ifndef SY_CONFLICT_ALL
+                if (((inv_any >> k) & 1u) == 0u) continue;
+#endif
                 const int tk = hbcast(tgt_v, k, upper);
                 const bool occ = hany(is_pol && pos_v == tk, upper);          // own node included (:231)
                 if (!occ && !skip_v && a == k) {

@@ -196,11 +196,14 @@ struct HalfScan {
     }
     template <int NR>
     __device__ __forceinline__ void eval_policy(const In& g, const Pol& pl, int H, int N, int lane, const float* w2_all,
-                                                const float* b2_all, int& act_v, int& cost_v, int& quirk_cnt, float& logp_v) {
+                                                const float* b2_all, uint32_t x_own, int& act_v, int& cost_v, int& quirk_cnt,
+                                                float& logp_v) {
+        // agent slot (16 B): [0..7] the winning entry — (ordered Gumbel key) << 32 | node | column << 10 | edge cost << 16,
+        // 0 = no affordable entry —, [8] max logit (ordered int), [12] sum of exp(logit - max)
         if (lanes(kAgentSlots)) {
-            *lds_at<uint64_t>(selr) = 0x0000ffffull;                                     // "no move": action -1, cost 0
+            lds_at<int>(selr)[1] = 0;                                                     // position-reward count
             typedef int v4i __attribute__((ext_vector_type(4)));
-            *lds_at<v4i>(pl.slr) = (v4i){(int)0x80000000, (int)0x80000000, 0, 0};         // max key, max logit, sum exp, log-prob
+            *lds_at<v4i>(pl.slr) = (v4i){0, 0, (int)0x80000000, 0};
         }
 #pragma unroll
         for (int k = 0; k < NC; ++k) *lds_at<uint8_t>(prev[k]) = 0;
@@ -288,24 +291,43 @@ struct HalfScan {
 #pragma unroll
             for (int k = 0; k < NC; ++k) l[k] = lanes(bo[k]) ? *lds_at<float>(pl.logits + 4u * eidx[k]) + bias[k] : 0.0f;
         }
+        // Gumbel-max draw: a cheap per-entry hash (ELL column) of the agent's Philox word of this step
+        auto gumbel = [](uint32_t x, uint32_t column) {
+            uint32_t h = x ^ (column * 0x9E3779B9u) ^ 0x85EBCA6Bu;
+            h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
+            const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            return -__logf(-__logf(u));
+        };
+        // the winner travels WITH its key: one 64-bit LDS max per entry, payload in the low word (no second hand-off)
+        auto entry_word = [&](float key, int k) {
+            const uint32_t uk = (uint32_t)f32_ordered(key) ^ 0x80000000u;               // unsigned order of the keys
+            const uint32_t pay = (g.ent[k] & 0x3ffu) | ((uint32_t)(k * GW + col) << 10) | (g.ent[k] & 0xffff0000u);
+            return ((uint64_t)uk << 32) | pay;
+        };
+        // ---- phase 1: the group's largest logit and its winning key, together
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+            if (lanes(bo[k])) {
+                atomicMax(lds_at_generic<int>(pl.sl + 8u), f32_ordered(l[k]));
+                atomicMax(lds_at_generic<unsigned long long>(pl.sl), (unsigned long long)entry_word(l[k] + gumbel(g.xa, (uint32_t)(k * GW + col)), k));
+            }
+        }
+        wave_lds_fence();
+        float Lm = ordered_f32(*lds_at<int>(pl.sl + 8u));
+        // ---- phase 2: the sum of exp(logit - max)
 #pragma unroll
         for (int k = 0; k < NC; ++k)
-            if (lanes(bo[k])) atomicMax(lds_at_generic<int>(pl.sl + 4u), f32_ordered(l[k]));
+            if (lanes(bo[k])) atomicAdd(lds_at_generic<float>(pl.sl + 12u), __expf(l[k] - Lm));
+        if (lanes(lead_m)) lds_at<int>(selw)[1] = __popc(qf);
         wave_lds_fence();
-        float Lm = ordered_f32(*lds_at<int>(pl.sl + 4u));
-#pragma unroll
-        for (int k = 0; k < NC; ++k)
-            if (lanes(bo[k])) atomicAdd(lds_at_generic<float>(pl.sl + 8u), __expf(l[k] - Lm));
-        wave_lds_fence();
-        float S = *lds_at<float>(pl.sl + 8u);
         // ---- the reference's underflow rule (mappo_agent.py:123-134), exact only where the cheap bound cannot rule it out
         {
+            const float S = *lds_at<float>(pl.sl + 12u);
             const bool lead = lanes(lead_m);
             const uint64_t sus = bal(lead && gf != 0u && !(Lm + __logf(S) > pl.thr));
-            uint64_t fb = 0ull;                       // groups (leader-lane bits) that fall back to uniform over the mask
 #ifndef SY_POL_NO_FALLBACK
             if (sus != 0ull) {                        // rare: evaluate the suspicious actors exactly, one (episode, agent) at a time
-                uint64_t todo = sus;
+                uint64_t fb = 0ull, todo = sus;       // groups (leader-lane bits) that fall back to uniform over the mask
                 while (todo != 0ull) {
                     const int ll = __ffsll((long long)todo) - 1;
                     todo &= todo - 1ull;
@@ -315,45 +337,35 @@ struct HalfScan {
                     const float mass = exact_legal_mass<NR>(w2_all + (size_t)agu * N * H, b2_all + (size_t)agu * N, hsu, H, N, lane, lse);
                     if (mass <= 1e-8f) fb |= 1ull << ll;
                 }
+                if (fb != 0ull) {                     // uniform over the mask: logits 0 -> keys = the Gumbel noise alone; redo the slot
+                    const bool f = ((fb >> (lane - col)) & 1ull) != 0ull;            // my group's leader bit -> my fallback flag
+                    if (f && lanes(lead_m)) {
+                        typedef int v4i __attribute__((ext_vector_type(4)));
+                        *lds_at<v4i>(pl.sl) = (v4i){0, 0, f32_ordered(0.0f), __float_as_int((float)__popc(gf))};
+                    }
+                    wave_lds_fence();
+#pragma unroll
+                    for (int k = 0; k < NC; ++k)
+                        if (f && lanes(bo[k]))
+                            atomicMax(lds_at_generic<unsigned long long>(pl.sl), (unsigned long long)entry_word(gumbel(g.xa, (uint32_t)(k * GW + col)), k));
+                    wave_lds_fence();
+                }
             }
 #endif
-            if (fb != 0ull) {                         // my group's leader bit -> my fallback flag
-                const bool f = ((fb >> (lane - col)) & 1ull) != 0ull;
-#pragma unroll
-                for (int k = 0; k < NC; ++k) l[k] = f ? 0.0f : l[k];
-                Lm = f ? 0.0f : Lm;
-                S = f ? (float)__popc(gf) : S;
-            }
         }
-        // Gumbel-max draw: a cheap per-entry hash (ELL column) of the agent's Philox word of this step
-        auto gumbel = [](uint32_t x, uint32_t column) {
-            uint32_t h = x ^ (column * 0x9E3779B9u) ^ 0x85EBCA6Bu;
-            h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-            const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
-            return -__logf(-__logf(u));
-        };
-        float key[NC];
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            key[k] = l[k] + gumbel(g.xa, (uint32_t)(k * GW + col));
-            if (lanes(bo[k])) atomicMax(lds_at_generic<int>(pl.sl), f32_ordered(key[k]));
+        // ---- the agent lanes read their slot: winner, max, sum -> action, cost, log-probability
+        {
+            typedef int v4i __attribute__((ext_vector_type(4)));
+            const v4i sv = *lds_at<v4i>(pl.slr);
+            const uint32_t pay = (uint32_t)sv.x, uk = (uint32_t)sv.y;
+            const bool any = (pay | uk) != 0u;
+            const float keyw = ordered_f32((int)(uk ^ 0x80000000u));
+            const float lw = keyw - gumbel(x_own, (pay >> 10) & 31u);                     // the winner's logit back from its key
+            act_v = any ? (int)(pay & 0x3ffu) : -1;
+            cost_v = any ? (int)(pay >> 16) : 0;
+            logp_v = any ? (lw - ordered_f32(sv.z)) - __logf(__int_as_float(sv.w)) : 0.0f;
+            quirk_cnt = lds_at<int>(selr)[1];
         }
-        wave_lds_fence();
-        const int kmax = *lds_at<int>(pl.sl);
-#pragma unroll
-        for (int k = 0; k < NC; ++k) {
-            if (lanes(bo[k]) && f32_ordered(key[k]) == kmax) {
-                *lds_at<int>(selw) = (int)g.ent[k];
-                *lds_at<float>(pl.sl + 12u) = (l[k] - Lm) - __logf(S);
-            }
-        }
-        if (lanes(lead_m)) lds_at<int>(selw)[1] = __popc(qf);
-        wave_lds_fence();
-        const uint64_t r = *lds_at<uint64_t>(selr);
-        act_v = (int)(int16_t)(uint32_t)r;              // 0xffff -> -1
-        cost_v = (int)(((uint32_t)r) >> 16);
-        quirk_cnt = (int)(r >> 32);
-        logp_v = *lds_at<float>(pl.slr + 12u);
         wave_lds_fence();
     }
 };
@@ -432,7 +444,7 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         if (POL) {
             policy_hidden_pair3(p, P, A, pos_v, lane, pol0, pol1);
             wave_lds_fence();
-            hs.template eval_policy<NR>(g0, hpl, p.pH, N, lane, p.pw2, p.pb2, act_v, cost_v, qcnt, logp_v);
+            hs.template eval_policy<NR>(g0, hpl, p.pH, N, lane, p.pw2, p.pb2, xw[0], act_v, cost_v, qcnt, logp_v);
         } else {
             hs.eval(g0, act_v, cost_v, qcnt);
         }
@@ -689,7 +701,7 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
         S3(3)
         // ---- evaluate half of the scan: masks of the new state, position-reward counts, next action
         if (HALF) {
-            if (POL) hs.template eval_policy<NR>(hg, hpl, p.pH, N, ln, p.pw2, p.pb2, act_v, cost_v, qcnt, logp_v);
+            if (POL) hs.template eval_policy<NR>(hg, hpl, p.pH, N, ln, p.pw2, p.pb2, x_next, act_v, cost_v, qcnt, logp_v);
             else hs.eval(hg, act_v, cost_v, qcnt);
         } else if (POL) {
             scan_eval_pair_policy3<NR>(psl, pll, sm, p.scan_w, p.pH, N, ln, p.pw2, p.pb2, sg, act_v, cost_v, qcnt, logp_v);

@@ -14,7 +14,7 @@ for every (env, agent) of a recorded rollout, with the engine-defined random str
     x = word (c & 3) of Philox4x32-7 block (global env id, c >> 2, ACT << 8 | agent) keyed with the stream key, c = the env's
     step counter before the step; the action is the entry with the largest key (logits 0 under the uniform fallback).
 
-Because the device evaluates logits and Gumbel noise in float32 (fast log), the restatement reports the float64 keys and the
+Because the device evaluates logits and Gumbel noise in float32 (fast log; u clamped below 1), the restatement reports the float64 keys and the
 top-2 MARGIN per (env, agent): wherever the margin exceeds the float32 error the recorded action must be the arg-max.
 """
 import numpy as np

@@ -375,7 +375,7 @@ __device__ __forceinline__ void scan_eval_pair_policy(PairScanLane& q, const Pol
     auto gumbel = [&sm](uint32_t x) {
         uint32_t h = x ^ ((uint32_t)sm.col * 0x9E3779B9u) ^ 0x85EBCA6Bu;
         h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-        const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u = fminf(((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f), 0x1.fffffep-1f);   // (h >> 8 = 2^24 - 1 rounds to 1.0f: -log(-log 1) = +inf)
         return -__logf(-__logf(u));
     };
     const float k0 = l0 + gumbel(g.xa0), k1 = l1 + gumbel(g.xa1);
@@ -636,7 +636,7 @@ __device__ __forceinline__ void scan_eval_pair_policy3(PairScanLane& q, const Po
     auto gumbel = [&sm](uint32_t x) {
         uint32_t h = x ^ ((uint32_t)sm.col * 0x9E3779B9u) ^ 0x85EBCA6Bu;
         h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-        const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u = fminf(((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f), 0x1.fffffep-1f);   // (h >> 8 = 2^24 - 1 rounds to 1.0f: -log(-log 1) = +inf)
         return -__logf(-__logf(u));
     };
     const float k0 = l0 + gumbel(g.xa0), k1 = l1 + gumbel(g.xa1);

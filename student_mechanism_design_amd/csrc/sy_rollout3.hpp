@@ -295,7 +295,7 @@ struct HalfScan {
         auto gumbel = [](uint32_t x, uint32_t column) {
             uint32_t h = x ^ (column * 0x9E3779B9u) ^ 0x85EBCA6Bu;
             h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16;
-            const float u = ((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f);
+            const float u = fminf(((float)(h >> 8) + 0.5f) * (1.0f / 16777216.0f), 0x1.fffffep-1f);   // (h >> 8 = 2^24 - 1 rounds to 1.0f: -log(-log 1) = +inf)
             return -__logf(-__logf(u));
         };
         // the winner travels WITH its key: one 64-bit LDS max per entry, payload in the low word (no second hand-off)

@@ -619,6 +619,29 @@ def test_fused_rollout_with_the_mappo_policy_in_the_kernel(sy):
     twin.close()
 
 
+def test_in_kernel_policy_log_probs_stay_finite(sy):
+    """The Gumbel noise of the draw is -log(-log(u)) with u = ((h >> 8) + 0.5) / 2^24 evaluated in float32: at
+    h >> 8 = 2^24 - 1 the float rounds to 1.0 and the noise to +inf, and the winner's logit (key - noise) to NaN — a
+    2^-24 event per affordable entry, i.e. about once per 256-step launch of the headline shape (seen first as a NaN
+    actor loss of the PPO update).  The engine clamps u below 1: over ~10^8 entry draws every recorded
+    log-probability is finite and <= 0."""
+    from student_mechanism_design_amd import policies as pol
+    N, P, B, T = 200, 4, 4096, 256
+    boards = sy.sample_board_pool(8, N, 400, seed=0)
+    env = sy.BatchedScotlandYardEnv(B, boards, P, 20, np.full(11, 0.5), seed=5, reveal_interval=5)
+    torch.manual_seed(0)
+    net = pol.MappoPolicy(N, P, hidden_size=64).to(env.device)
+    env.set_policy(pol.DeviceMappoPolicy(net, seed=3))
+    out = env.alloc_rollout(T, record_mask=False, record_belief=False)
+    for _ in range(6):
+        rec = env.rollout(T, out=out, record_mask=False, record_belief=False)
+        lp = rec["log_prob"]
+        assert bool(torch.isfinite(lp).all()), int((~torch.isfinite(lp)).sum())
+        assert float(lp.max()) <= 1e-5
+    env.check_status()
+    env.close()
+
+
 @pytest.mark.parametrize("N,P,H,B,E", [(60, 2, 32, 50, None), (90, 6, 16, 31, None), (24, 3, 64, 9, None), (140, 5, 64, 40, None),
                                        (200, 6, 128, 24, 400), (150, 7, 32, 18, None), (40, 6, 64, 16, 75), (100, 4, 128, 33, None)])
 def test_in_kernel_policy_other_shapes(sy, N, P, H, B, E):

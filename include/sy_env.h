@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SY_ABI_VERSION 5
+#define SY_ABI_VERSION 6
 #define SY_ELL_WIDTH 16
 #define SY_MAX_AGENTS 8
 #define SY_MAX_NODES 1024
@@ -285,6 +285,44 @@ typedef struct sy_returns_args {
     void *returns, *adv;
 } sy_returns_args;
 int sy_returns_advantages(const sy_returns_args *args, void *stream);
+
+/* replaces the loss + backward of MappoAgent.ppo_update (agent/mappo_agent.py:260-293) for one minibatch of a rollout
+ * record, in one launch (+ a reduction launch): the clipped surrogate (epsilon `clip`) of every agent's recorded action
+ * under its actor — the masked, renormalised softmax of select_action (mappo_agent.py:112-134) over the affordable
+ * entries of the agent's ELL row — averaged over num_rows * A, plus value_coef * the central critic's MSE against
+ * `team_ret`, and the gradient of that sum with respect to every parameter.  All pointers device.
+ *   record   [R][record_words] packed rollout rows (sy_rollout_buffers.record): pos, budget, action are read in place
+ *   log_prob [R][A] recorded log-probabilities, adv [R][A] (standardised) advantages, team_ret [R] critic targets
+ *   rows     [num_rows] int32 row indices of the minibatch, or NULL = rows row0 .. row0 + num_rows - 1;
+ *            row r belongs to env r % num_envs (records are [T][B]); env_graph [num_envs], ell uint32 [G][N][16]
+ *   w1t [A][N][H], b1 [A][H], w2 [A][N][H] (torch's layout), b2 [A][N]: the actors;  critic: c1m [N][H] = first layer's
+ *   MrX block transposed, c1p [N][H] = the SUM of its P police blocks transposed (the critic's input repeats the police
+ *   multi-hot P times, mappo_trainer.py:197-208), cb1 [H], c2 [H], cb2 [1]
+ *   grads [A + 1][S], S = sy_ppo_slab_floats(N, H): role a < A = actor a: d w1t[a] (N*H) | d w2[a] (N*H) | d b1[a] (H) |
+ *   d b2[a] (N, padded to DN = max(N, H) rounded up to 4) | 8 floats: [0] = actor a's share of the actor loss;
+ *   role A = critic: d c1m | d c1p (the gradient of EACH police block) | d cb1 | d c2 (H, padded to DN) | [0] = critic
+ *   loss (MSE, without value_coef), [1] = d cb2.   scratch: sy_ppo_scratch_floats(A, N, H) floats.
+ * Limits: hidden a multiple of 4, at most 128.  Sums are accumulated in float64 (LDS), in a different order than a BLAS
+ * matmul: parity with the torch form is to float32 rounding. */
+typedef struct sy_ppo_args {
+    const int32_t *record;
+    int32_t record_words;
+    const float *log_prob, *adv, *team_ret;
+    const int32_t *rows;
+    int32_t row0, num_rows, num_envs;
+    const uint32_t *ell;
+    const int32_t *env_graph;
+    int32_t num_police, num_nodes, hidden;
+    const float *w1t, *b1, *w2, *b2;
+    const float *c1m, *c1p, *cb1, *c2, *cb2;
+    float clip, value_coef;
+    float *scratch;
+    int64_t scratch_floats;
+    float *grads;
+} sy_ppo_args;
+int32_t sy_ppo_slab_floats(int32_t num_nodes, int32_t hidden);
+int64_t sy_ppo_scratch_floats(int32_t num_agents, int32_t num_nodes, int32_t hidden);
+int sy_mappo_ppo_grad(const sy_ppo_args *args, void *stream);
 
 /* replaces Pathfinder.get_distance (pathfinding.py:34-137) for a whole pool: all-pairs weighted
  * shortest paths from the ELL table, apsp uint16 [G][N][N] (0xFFFF = unreachable); all device */

@@ -11,7 +11,7 @@ MAX_AGENTS = 8
 MAX_NODES = 1024
 NUM_WEIGHTS = 11
 MRX_MONEY = 1000
-ABI_VERSION = 5
+ABI_VERSION = 6
 STATUS_BELIEF_WAIT_EXPIRED = 1
 STATUS_RING_WAIT_EXPIRED = 2
 
@@ -48,6 +48,16 @@ class ReturnsArgs(C.Structure):
                 ("adv", C.c_void_p)]
 
 
+class PpoArgs(C.Structure):
+    _fields_ = [("record", C.c_void_p), ("record_words", C.c_int32), ("log_prob", C.c_void_p), ("adv", C.c_void_p),
+                ("team_ret", C.c_void_p), ("rows", C.c_void_p), ("row0", C.c_int32), ("num_rows", C.c_int32),
+                ("num_envs", C.c_int32), ("ell", C.c_void_p), ("env_graph", C.c_void_p), ("num_police", C.c_int32),
+                ("num_nodes", C.c_int32), ("hidden", C.c_int32), ("w1t", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p),
+                ("b2", C.c_void_p), ("c1m", C.c_void_p), ("c1p", C.c_void_p), ("cb1", C.c_void_p), ("c2", C.c_void_p),
+                ("cb2", C.c_void_p), ("clip", C.c_float), ("value_coef", C.c_float), ("scratch", C.c_void_p),
+                ("scratch_floats", C.c_int64), ("grads", C.c_void_p)]
+
+
 class RolloutBuffers(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("record", "mask", "belief", "log_prob")]
 
@@ -57,7 +67,8 @@ EXPORTS = ["sy_abi_version", "sy_record_words", "sy_last_error", "sy_env_create"
            "sy_env_step", "sy_env_step_record", "sy_env_rollout", "sy_action_mask_dense", "sy_belief_update", "sy_build_apsp", "sy_sample_boards",
            "sy_masked_categorical_sample", "sy_mappo_policy_act", "sy_env_bind_status", "sy_env_status",
            "sy_returns_advantages", "sy_build_id", "sy_env_rollout_kernel_name",
-           "sy_gnn_padded_features", "sy_gnn_param_floats", "sy_gnn_q_act"]
+           "sy_gnn_padded_features", "sy_gnn_param_floats", "sy_gnn_q_act",
+           "sy_ppo_slab_floats", "sy_ppo_scratch_floats", "sy_mappo_ppo_grad"]
 
 _lib = None
 
@@ -103,10 +114,14 @@ def load():
     lib.sy_sample_boards.argtypes = [i32, i32, i32, i32, u64, i32, vp, vp, vp, vp, vp, i32, vp]
     lib.sy_masked_categorical_sample.argtypes = [vp, C.c_int64, vp, C.c_int64, i32, i32, u64, u64, vp, i32, vp, vp, vp, vp]
     lib.sy_mappo_policy_act.argtypes = [vp, vp, C.c_int64, C.POINTER(MappoWeights), i32, i32, i32, i32, u64, u64, vp, vp, vp, vp, vp, vp]
+    lib.sy_ppo_slab_floats.argtypes = [i32, i32]
+    lib.sy_ppo_scratch_floats.argtypes = [i32, i32, i32]
+    lib.sy_mappo_ppo_grad.argtypes = [C.POINTER(PpoArgs), vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("sy_last_error", "sy_build_id"):
             fn.restype = C.c_int
+    lib.sy_ppo_scratch_floats.restype = C.c_int64
     if lib.sy_abi_version() != ABI_VERSION:
         raise EngineError(f"libsy_env.so ABI {lib.sy_abi_version()} != expected {ABI_VERSION}; rebuild it")
     _lib = lib

@@ -20,7 +20,7 @@ OBJ_ROOT = os.path.join(CSRC, "_obj")
 # translation units, the slowest first (the scheduler starts them in this order)
 SOURCES = ["sy_rollout3_p.hip", "sy_rollout3_q.hip", "sy_rollout2_c.hip", "sy_rollout1_b.hip", "sy_rollout2_a.hip", "sy_rollout1_a.hip",
            "sy_rollout3_a.hip", "sy_rollout3_b.hip", "sy_rollout3_c.hip", "sy_rollout3_d.hip", "sy_rollout2_b.hip",
-           "sy_policy.hip", "sy_aux.hip", "sy_step.hip", "sy_gnn.hip", "sy_returns.hip", "sy_dispatch.hip", "sy_capi.hip"]
+           "sy_policy.hip", "sy_aux.hip", "sy_step.hip", "sy_gnn.hip", "sy_ppo.hip", "sy_returns.hip", "sy_dispatch.hip", "sy_capi.hip"]
 HEADERS = {
     "sy_kernels.h": ["sy_kernels.h", os.path.join("..", "..", "include", "sy_env.h")],
     "sy_device.hpp": ["sy_device.hpp", "@sy_kernels.h"],

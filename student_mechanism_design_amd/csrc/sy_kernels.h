@@ -115,6 +115,23 @@ hipError_t launch_mappo_policy(const int32_t* pos, const uint8_t* mask, long lon
                                const uint64_t* offset_dev, int32_t* action, float* log_prob, float* value, float* probs_out,
                                hipStream_t stream);
 
+// one PPO minibatch of the MAPPO networks: loss + gradient (sy_ppo.hip, sy_mappo_ppo_grad)
+struct PpoArgs {
+    const int32_t* record; int32_t RW;
+    const float* log_prob; const float* adv; const float* team_ret;
+    const int32_t* rows; int32_t row0, mb, B;
+    const uint32_t* ell; const int32_t* env_graph;
+    int32_t A, N, H;
+    const float *w1t, *b1, *w2, *b2, *c1m, *c1p, *cb1, *c2, *cb2;
+    float clip, value_coef;
+    float* partial;
+    int32_t DN, slab, parts, rpp;     // filled by the launcher (parts: row ranges a table is cut into; rpp: rows per part)
+};
+int ppo_slab_floats(int N, int H);
+int ppo_parts(int N, int H);
+int ppo_blocks_per_role(int A, int N, int H);
+hipError_t launch_ppo_grad(PpoArgs a, float* grads, hipStream_t stream);
+
 // the GNN Q-policy (sy_gnn.hip)
 int gnn_padded_features(int F);
 int gnn_param_floats(int F);

@@ -1,0 +1,443 @@
+// sy_ppo.hip — one PPO minibatch of the MAPPO networks: loss AND gradient in one launch (sy_mappo_ppo_grad).
+//
+// What it replaces: the loss + backward of MappoAgent.ppo_update (/root/reference/src/agent/mappo_agent.py:247-293) as
+// student_mechanism_design_amd/update.py::MappoUpdater._losses states it batched over a rollout record — the clipped
+// surrogate (epsilon `clip`) of every agent's own action under its actor, on the masked, renormalised softmax of
+// select_action (mappo_agent.py:112-134), and the central critic's MSE against the team return.  The torch form builds
+// [A, mb, N] logits (131 MB per 32 768-row minibatch), gathers <= 16 of the 200 columns and runs ~100 kernels forward and
+// backward: 1.9 ms per minibatch on MI355X.  Here every (row, agent) evaluates only what the loss reads:
+//
+//   h      = relu(b1 + sum of the W1t rows of the observation's nodes)           (one-hot MrX node / multi-hot police nodes)
+//   l_e    = b2[n_e] + W2[n_e] . h     for the AFFORDABLE entries e of the agent's ELL row only (<= 16, ~3 on average)
+//   new_lp = l_act - logsumexp_e l_e;  ratio, clipped surrogate;  d l_e = G (1[e = act] - p_e)
+//   dW2[n_e] += d l_e h;  db2[n_e] += d l_e;  dh = sum_e d l_e W2[n_e];  dz = dh [z > 0];  dW1t[node] += dz;  db1 += dz
+//
+// Grid: a block owns ONE of a network's two [N][H] gradient tables (A actors + the critic: 2 (A + 1) roles; tables larger
+// than the LDS are cut into row ranges, one role each) and keeps it in LDS as float64 — 102 KB at N = 200, H = 64 —, so
+// every update is an LDS add; both blocks of a network run the forward pass (it is cheap: the adds are the cost).  Blocks
+// write their tables to a partial buffer, a second kernel sums the partials (no global atomics).
+// Lane layout: every 16-lane group of a wave works on its own row (four rows per wave in flight), lane j of the group
+// holding 16-byte piece j of the hidden vector (pieces j, j + 16 for hidden > 64): a table row is one 256-byte request of
+// the group, a dot product 4 FMAs + 4 DPP steps inside the group, the softmax over the affordable entries a DPP reduction
+// with entry j's logit on lane j.  The loop is a chain of dependent lookups (row index -> record words -> ELL row + W1t
+// rows -> W2 rows): the first two hops are prefetched one iteration ahead, the W2 rows of four entries are in flight
+// together, and 16 waves per CU overlap the rest.  Summation order differs from a BLAS matmul: parity with the torch form
+// is to float32 rounding (tests: 1e-4 relative on every gradient).
+#include "sy_device.hpp"
+
+namespace sy {
+
+typedef float ppo_f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float row16_sum(float v) {     // every lane of a 16-lane group gets the group's sum
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x124>(v);
+    v += dpp_mov<0x128>(v);
+    return v;
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x124>(v));
+    v = fmaxf(v, dpp_mov<0x128>(v));
+    return v;
+}
+// The gradient tables are float64 in LDS.  On gfx950 ds_add_f32 runs ~20x slower than ds_add_u32 / ds_add_f64
+// (tools/probes/lds_atomic_probe.hip: 12 363 vs 606 / 634 ticks for 16 bytes per lane from 16 waves) — the first version
+// of this kernel, float32 tables, spent 2.7 of its 3.3 ms in them.  float64 adds run at the integer rate and make the
+// sums independent of the order the waves arrive in (to float32 rounding of the final value).
+__device__ __forceinline__ void lds_add(double* p, float v) {
+#if defined(SY_PPO_DIAG_NO_ADD)          // timing-only diagnostic (wrong results): what do the LDS atomics cost?
+    asm volatile("" ::"v"(p), "v"(v));
+#else
+    __hip_atomic_fetch_add(p, (double)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+__device__ __forceinline__ void lds_add4(double* p, ppo_f4 v) {
+    lds_add(p, v.x); lds_add(p + 1, v.y); lds_add(p + 2, v.z); lds_add(p + 3, v.w);
+}
+__device__ __forceinline__ float dot4(ppo_f4 a, ppo_f4 b) {
+    return fmaf(a.w, b.w, fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)));
+}
+__device__ __forceinline__ ppo_f4 relu4(ppo_f4 z) {
+    ppo_f4 h;
+    h.x = fmaxf(z.x, 0.0f); h.y = fmaxf(z.y, 0.0f); h.z = fmaxf(z.z, 0.0f); h.w = fmaxf(z.w, 0.0f);
+    return h;
+}
+__device__ __forceinline__ ppo_f4 gate4(ppo_f4 z, ppo_f4 d) {    // d where z > 0
+    ppo_f4 o;
+    o.x = z.x > 0.0f ? d.x : 0.0f; o.y = z.y > 0.0f ? d.y : 0.0f; o.z = z.z > 0.0f ? d.z : 0.0f; o.w = z.w > 0.0f ? d.w : 0.0f;
+    return o;
+}
+
+// What a group needs of its row before any table lookup: prefetched one iteration ahead (two dependent loads — the
+// minibatch's row index, then the record words — that would otherwise head every iteration's chain of loads).
+struct PpoRow {
+    int r;          // record row
+    int posv;       // lane j < A: node of agent j before the step
+    int bud, act;   // the actor's agent: budget before the step, recorded action
+    float olp, adv; // recorded log-probability, advantage           (critic: adv = the team return)
+    int g;          // board of the row's env
+    bool on;        // the group has a row (the tail of a minibatch may not fill all four groups)
+};
+template <bool ACTOR>
+__device__ __forceinline__ PpoRow ppo_fetch_row(const PpoArgs& p, int i, int a, int j) {
+    PpoRow w;
+    w.on = i < p.mb;
+    const int ii = w.on ? i : p.mb - 1;
+    w.r = p.rows ? p.rows[ii] : p.row0 + ii;
+    const int A = p.A;
+    const int32_t* const rec = p.record + (size_t)w.r * p.RW;
+    w.posv = j < A ? rec[2 * A + j] : 0;
+    if (ACTOR) {
+        w.bud = rec[3 * A + a];
+        w.act = rec[4 * A + a];
+        w.olp = p.log_prob[(size_t)w.r * A + a];
+        w.adv = p.adv[(size_t)w.r * A + a];
+        w.g = p.env_graph[w.r % p.B];
+    } else {
+        w.bud = 0; w.act = 0; w.olp = 0.0f; w.g = 0;
+        w.adv = p.team_ret[w.r];
+    }
+    return w;
+}
+
+template <int KP, int KEEP>   // KP: 16-byte pieces of a hidden vector per lane, 1 (hidden <= 64) or 2 (<= 128);
+                              // KEEP: rounds of four W2 rows kept in registers for the backward pass
+__global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
+    extern __shared__ double acc[];
+    const int N = p.N, H = p.H, NH = N * H, A = p.A, P = A - 1;
+    // blockIdx.y = ((network * 2) + table) * parts + part: this block accumulates rows [n0, n1) of ONE table of one network
+    const int role = blockIdx.y / (2 * p.parts);                      // network: actor a < A, or the critic (A)
+    const int tab = (blockIdx.y / p.parts) & 1, part = blockIdx.y % p.parts;
+    const int n0 = part * p.rpp, n1 = min(N, n0 + p.rpp);
+    double* const gT = acc;                              // table 0: d W1t[a] (critic: d C1m, the first layer's MrX block); table 1: d W2[a]
+                                                         // (critic: d C1p, every police block's gradient); rows n0 .. n1 - 1, [H] each
+    double* const gC = acc + (size_t)p.rpp * H;          // [H]   d b1[a] (table 0, part 0)            critic: d cb1
+    double* const gD = gC + H;                           // [DN]  d b2[a] ([N]; table 1, part 0)       critic: d c2 ([H]; table 0, part 0)
+    double* const gE = gD + p.DN;                        // [8]   0: loss sum (actor: table 1 part 0; critic: table 0 part 0), 1: d cb2
+    const bool smalls = part == 0 && tab == (role < A ? 1 : 0);   // this block also owns the loss (+ b2 / critic head) sums
+    const bool own_b1 = part == 0 && tab == 0;                    // ... the first layer's bias sums
+    {
+        const int tot = p.rpp * H + H + p.DN + 8;
+        for (int k = threadIdx.x; k < tot; k += blockDim.x) acc[k] = 0.0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
+    const int u = lane >> 4, j = lane & 15;          // group u of the wave works on its own row; j: piece of the hidden vector
+    const int nq = H >> 2;
+    int pk[KP];
+    bool pv[KP];
+#pragma unroll
+    for (int m = 0; m < KP; ++m) {
+        pv[m] = j + 16 * m < nq;
+        pk[m] = pv[m] ? 4 * (j + 16 * m) : 0;
+    }
+    const ppo_f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int stride = gridDim.x * W * 4;
+    int i = (blockIdx.x * W + wave) * 4 + u;
+    float loss = 0.0f;
+    if (role < A) {
+        // ---------------------------------------------------------------- actor `role`
+        const int a = role;
+        const float* const w1 = p.w1t + (size_t)a * NH;
+        const float* const w2 = p.w2 + (size_t)a * NH;
+        const float* const b2 = p.b2 + (size_t)a * N;
+        const int nit = a == 0 ? 1 : P;                      // nodes of the observation: MrX's / all police
+        const float inv = 1.0f / ((float)p.mb * (float)A);
+        const float lo = 1.0f - p.clip, hi = 1.0f + p.clip;
+        ppo_f4 b1p[KP], gb1[KP];
+#pragma unroll
+        for (int m = 0; m < KP; ++m) {
+            b1p[m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(p.b1 + (size_t)a * H + pk[m]) : zero4;
+            gb1[m] = zero4;
+        }
+        PpoRow nx = ppo_fetch_row<true>(p, i, a, j);
+        for (; __builtin_amdgcn_readfirstlane(i - u) < p.mb; i += stride) {
+            const PpoRow rw = nx;
+            nx = ppo_fetch_row<true>(p, i + stride, a, j);
+            const int node_a = __shfl(rw.posv, a, 16);
+            // the agent's ELL row: lane j holds entry j; affordable entries compacted to lanes 0 .. n - 1 of the group
+            const uint32_t ent = p.ell[((size_t)rw.g * N + node_a) * SY_ELL_WIDTH + j];
+            // hidden vector (the W1t rows of the observation's nodes: independent loads, issued together with the ELL row)
+            ppo_f4 z[KP], h[KP];
+#pragma unroll
+            for (int m = 0; m < KP; ++m) z[m] = b1p[m];
+            for (int it = 0; it < nit; ++it) {
+                const int node = __shfl(rw.posv, a == 0 ? 0 : 1 + it, 16);
+#pragma unroll
+                for (int m = 0; m < KP; ++m)
+                    if (pv[m]) z[m] += *reinterpret_cast<const ppo_f4*>(w1 + (size_t)node * H + pk[m]);
+            }
+#pragma unroll
+            for (int m = 0; m < KP; ++m) h[m] = relu4(z[m]);
+            const bool legal = rw.on && (int)(ent >> 16) <= rw.bud;
+            const uint32_t L = (uint32_t)(bal(legal) >> (16 * u)) & 0xffffu;
+            const int n = __popc(L);
+            const int below = __popc(L & ((1u << j) - 1u));
+            const int dstl = legal ? below : n + (j - below);                  // a permutation of the group's lanes
+            const uint32_t cent = (uint32_t)__builtin_amdgcn_ds_permute((16 * u + dstl) << 2, (int)ent);
+            const int nbj = (int)(cent & 0xffffu);                               // lane j < n: node of affordable entry j
+            const int nmax = __builtin_amdgcn_readfirstlane(max(max(__shfl(n, 0), __shfl(n, 16)), max(__shfl(n, 32), __shfl(n, 48))));
+            // logits: entry e of every group per step, four steps' rows in flight; lane j keeps the logit of entry j
+            ppo_f4 wk[KEEP > 0 ? KEEP : 1][4][KP];
+            float lgj = -3.0e38f;
+            for (int c = 0; 4 * c < nmax; ++c) {
+                ppo_f4 wq[4][KP];
+                int nbe[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int e = 4 * c + t;
+                    nbe[t] = __shfl(nbj, e < n ? e : 0, 16);
+                    nbe[t] = n > 0 ? nbe[t] : 0;
+#pragma unroll
+                    for (int m = 0; m < KP; ++m)
+                        wq[t][m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(w2 + (size_t)nbe[t] * H + pk[m]) : zero4;
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int e = 4 * c + t;
+                    float d = 0.0f;
+#pragma unroll
+                    for (int m = 0; m < KP; ++m) d += dot4(wq[t][m], h[m]);
+                    d = row16_sum(d);
+                    lgj = (j == e && e < n) ? d : lgj;
+                }
+#pragma unroll
+                for (int k = 0; k < KEEP; ++k) {
+                    if (c == k) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int m = 0; m < KP; ++m) wk[k][t][m] = wq[t][m];
+                    }
+                }
+            }
+            const bool mine = j < n;
+            if (mine) lgj += b2[nbj];
+            const float mx = row16_max(mine ? lgj : -3.0e38f);
+            const float ex = mine ? expf(lgj - mx) : 0.0f;
+            const float se = row16_sum(ex);
+            const bool hit = mine && nbj == rw.act;
+            const float cm = row16_sum(hit ? 1.0f : 0.0f);
+            const float la = row16_sum(hit ? lgj : 0.0f);
+            // clipped surrogate (mappo_agent.py:284-291) and its derivative with respect to the new log-probability
+            const bool valid = rw.act >= 0 && cm > 0.0f;          // an agent without a legal action: ratio 1, no gradient
+            const float lse = valid ? mx + logf(se) : 0.0f;
+            const float icm = valid ? 1.0f / cm : 0.0f;
+            const float new_lp = valid ? la * icm - lse : 0.0f;
+            const float ratio = expf(new_lp - (valid ? rw.olp : 0.0f));
+            const float s1 = ratio * rw.adv, s2 = fminf(fmaxf(ratio, lo), hi) * rw.adv;
+            if (rw.on && j == 0) loss -= fminf(s1, s2) * inv;
+            const bool within = ratio >= lo && ratio <= hi;
+            const float G = (rw.on && valid && (within || s1 < s2)) ? -inv * rw.adv * ratio : 0.0f;   // (a clipped sample has no gradient)
+            const float dlj = (mine && G != 0.0f) ? G * ((hit ? icm : 0.0f) - expf(lgj - lse)) : 0.0f;              // d loss / d logit of entry j
+            if (bal(G != 0.0f) != 0ull) {
+                if (smalls && mine && G != 0.0f) lds_add(gD + nbj, dlj);
+                ppo_f4 dh[KP];
+#pragma unroll
+                for (int m = 0; m < KP; ++m) dh[m] = zero4;
+                for (int c = 0; 4 * c < nmax; ++c) {
+                    ppo_f4 wq[4][KP];
+                    int nbe[4];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int e = 4 * c + t;
+                        nbe[t] = __shfl(nbj, e < n ? e : 0, 16);
+                        nbe[t] = n > 0 ? nbe[t] : 0;
+                    }
+                    if (c < KEEP) {
+#pragma unroll
+                        for (int k = 0; k < KEEP; ++k)
+                            if (c == k) {
+#pragma unroll
+                                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                                    for (int m = 0; m < KP; ++m) wq[t][m] = wk[k][t][m];
+                            }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t)
+#pragma unroll
+                            for (int m = 0; m < KP; ++m)
+                                wq[t][m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(w2 + (size_t)nbe[t] * H + pk[m]) : zero4;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const int e = 4 * c + t;
+                        float dl = __shfl(dlj, e < n ? e : 0, 16);
+                        dl = e < n ? dl : 0.0f;
+#pragma unroll
+                        for (int m = 0; m < KP; ++m) dh[m] += dl * wq[t][m];
+                        if (tab == 1 && dl != 0.0f && nbe[t] >= n0 && nbe[t] < n1) {
+#pragma unroll
+                            for (int m = 0; m < KP; ++m)
+                                if (pv[m]) lds_add4(gT + (size_t)(nbe[t] - n0) * H + pk[m], dl * h[m]);
+                        }
+                    }
+                }
+                ppo_f4 dz[KP];
+#pragma unroll
+                for (int m = 0; m < KP; ++m) {
+                    dz[m] = gate4(z[m], dh[m]);
+                    gb1[m] += dz[m];
+                }
+                if (tab == 0) {
+                    for (int it = 0; it < nit; ++it) {
+                        const int node = __shfl(rw.posv, a == 0 ? 0 : 1 + it, 16);
+                        if (G != 0.0f && node >= n0 && node < n1) {
+#pragma unroll
+                            for (int m = 0; m < KP; ++m)
+                                if (pv[m]) lds_add4(gT + (size_t)(node - n0) * H + pk[m], dz[m]);
+                        }
+                    }
+                }
+            }
+        }
+        if (own_b1) {
+#pragma unroll
+            for (int m = 0; m < KP; ++m)
+                if (pv[m]) lds_add4(gC + pk[m], gb1[m]);
+        }
+    } else {
+        // ---------------------------------------------------------------- the central critic (mappo_agent.py:32-44, :260-265)
+        const float inv = 1.0f / (float)p.mb;
+        ppo_f4 cb1p[KP], c2p[KP], gcb1[KP], gc2[KP];
+#pragma unroll
+        for (int m = 0; m < KP; ++m) {
+            cb1p[m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(p.cb1 + pk[m]) : zero4;
+            c2p[m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(p.c2 + pk[m]) : zero4;
+            gcb1[m] = zero4;
+            gc2[m] = zero4;
+        }
+        const float cb2 = p.cb2[0];
+        float gcb2 = 0.0f;
+        PpoRow nx = ppo_fetch_row<false>(p, i, 0, j);
+        for (; __builtin_amdgcn_readfirstlane(i - u) < p.mb; i += stride) {
+            const PpoRow rw = nx;
+            nx = ppo_fetch_row<false>(p, i + stride, 0, j);
+            ppo_f4 z[KP], hc[KP];
+#pragma unroll
+            for (int m = 0; m < KP; ++m) z[m] = cb1p[m];
+            for (int it = 0; it < A; ++it) {                         // item 0: MrX's node on c1m; items 1..P: police nodes on c1p
+                const int node = __shfl(rw.posv, it, 16);
+                const float* const tab = it == 0 ? p.c1m : p.c1p;
+#pragma unroll
+                for (int m = 0; m < KP; ++m)
+                    if (pv[m]) z[m] += *reinterpret_cast<const ppo_f4*>(tab + (size_t)node * H + pk[m]);
+            }
+            float d = 0.0f;
+#pragma unroll
+            for (int m = 0; m < KP; ++m) {
+                hc[m] = relu4(z[m]);
+                d += dot4(c2p[m], hc[m]);
+            }
+            const float err = rw.on ? row16_sum(d) + cb2 - rw.adv : 0.0f;
+            if (j == 0) {
+                loss += err * err * inv;
+                gcb2 += p.value_coef * 2.0f * err * inv;
+            }
+            const float dv = p.value_coef * 2.0f * err * inv;
+            ppo_f4 dz[KP];
+#pragma unroll
+            for (int m = 0; m < KP; ++m) {
+                gc2[m] += dv * hc[m];
+                dz[m] = gate4(z[m], dv * c2p[m]);
+                gcb1[m] += dz[m];
+            }
+            for (int it = tab; it < (tab == 0 ? 1 : A); ++it) {      // table 0: MrX's node; table 1: the police nodes
+                const int node = __shfl(rw.posv, it, 16);
+                if (rw.on && node >= n0 && node < n1) {
+#pragma unroll
+                    for (int m = 0; m < KP; ++m)
+                        if (pv[m]) lds_add4(gT + (size_t)(node - n0) * H + pk[m], dz[m]);
+                }
+            }
+        }
+        if (smalls) {
+#pragma unroll
+            for (int m = 0; m < KP; ++m) {
+                if (pv[m]) {
+                    lds_add4(gC + pk[m], gcb1[m]);
+                    lds_add4(gD + pk[m], gc2[m]);
+                }
+            }
+            if (j == 0) lds_add(gE + 1, gcb2);
+        }
+    }
+    if (smalls && j == 0) lds_add(gE, loss);
+    __syncthreads();
+    // this block's share of the network's slab [d table 0 (N*H) | d table 1 (N*H) | H | DN | 8]: every region has one owner
+    float* const dst = p.partial + ((size_t)blockIdx.x * (A + 1) + role) * p.slab;
+    {
+        float* const dt = dst + (size_t)tab * NH + (size_t)n0 * H;
+        const int cnt = (n1 - n0) * H;
+        for (int k = threadIdx.x; k < cnt; k += blockDim.x) dt[k] = (float)gT[k];
+    }
+    if (role < A ? own_b1 : smalls)
+        for (int k = threadIdx.x; k < H; k += blockDim.x) dst[2 * NH + k] = (float)gC[k];
+    if (smalls)
+        for (int k = threadIdx.x; k < p.DN + 8; k += blockDim.x) dst[2 * NH + H + k] = (float)gD[k];
+}
+
+// grads[t] = sum over the blocks of a role of their partial tables
+__global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict__ partial, int nb, int total, float* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+    int b = 0;
+    for (; b + 4 <= nb; b += 4) {
+        s0 += partial[(size_t)b * total + t];
+        s1 += partial[(size_t)(b + 1) * total + t];
+        s2 += partial[(size_t)(b + 2) * total + t];
+        s3 += partial[(size_t)(b + 3) * total + t];
+    }
+    for (; b < nb; ++b) s0 += partial[(size_t)b * total + t];
+    out[t] = (s0 + s1) + (s2 + s3);
+}
+
+// ---- launchers
+int ppo_slab_floats(int N, int H) {
+    const int dn = ((N > H ? N : H) + 3) & ~3;
+    return 2 * N * H + H + dn + 8;
+}
+// rows of one [N][H] float64 table a block can hold beside the small vectors (one block per CU: 160 KB of LDS)
+static int ppo_rows_per_part(int N, int H) {
+    const int dn = ((N > H ? N : H) + 3) & ~3;
+    const long long room = 160 * 1024 - (long long)(H + dn + 8) * 8;
+    long long rpp = room / ((long long)H * 8);
+    if (rpp > N) rpp = N;
+    return (int)rpp;
+}
+int ppo_parts(int N, int H) {
+    const int rpp = ppo_rows_per_part(N, H);
+    return rpp < 1 ? 0 : (N + rpp - 1) / rpp;
+}
+int ppo_blocks_per_role(int A, int N, int H) {
+    const int parts = ppo_parts(N, H);
+    const int nb = 256 / (2 * (A + 1) * (parts < 1 ? 1 : parts));    // one 1024-thread block per CU: 256 CUs
+    return nb < 1 ? 1 : nb;
+}
+
+hipError_t launch_ppo_grad(PpoArgs a, float* grads, hipStream_t stream) {
+    a.DN = ((a.N > a.H ? a.N : a.H) + 3) & ~3;
+    a.slab = ppo_slab_floats(a.N, a.H);
+    a.parts = ppo_parts(a.N, a.H);
+    if (a.parts < 1) return hipErrorInvalidValue;
+    a.rpp = (a.N + a.parts - 1) / a.parts;           // balanced parts
+    int nb = ppo_blocks_per_role(a.A, a.N, a.H);
+    const int need = (a.mb + 63) / 64;          // a 16-wave block takes 64 rows per pass
+    if (nb > need) nb = need;
+    const size_t lds = ((size_t)a.rpp * a.H + a.H + a.DN + 8) * sizeof(double);
+    const dim3 grid(nb, 2 * (a.A + 1) * a.parts);
+    if (a.H <= 64) hipLaunchKernelGGL((ppo_grad_kernel<1, 2>), grid, dim3(1024), lds, stream, a);
+    else hipLaunchKernelGGL((ppo_grad_kernel<2, 0>), grid, dim3(1024), lds, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const int total = (a.A + 1) * a.slab;
+    hipLaunchKernelGGL(ppo_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, a.partial, nb, total, grads);
+    return hipGetLastError();
+}
+
+}  // namespace sy

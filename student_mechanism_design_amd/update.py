@@ -14,7 +14,15 @@ What makes it fast (round 2's plain-torch form spent 35.7 ms per update of 1.3 M
     from the logits with the board table) — the masked, renormalised softmax of `select_action` (mappo_agent.py:112-134)
     without ever forming [mb, A, N] probability / mask tensors;
   * one fused Adam step per minibatch; optionally the whole minibatch step replayed as ONE HIP graph (`use_graph`).
+
+`fused=True` (the default on a GPU) goes further: loss AND gradient of
+a minibatch come from ONE HIP kernel, `sy_mappo_ppo_grad` (include/sy_env.h, csrc/sy_ppo.hip), which reads the packed
+rollout record in place through the minibatch's row indices (no shuffled copy of the record), evaluates only the
+affordable logits of every (row, agent) and accumulates each network's gradient in LDS.  torch keeps what it is good at:
+the parameters, Adam, and the few small copies between its layouts and the kernel's.  The torch form above stays as
+`fused=False` — the restatement the kernel is tested against (tests/test_gpu_surface.py).
 """
+import ctypes as C
 from typing import Dict, Optional
 
 import torch
@@ -47,8 +55,11 @@ class _OneHotLinear(torch.autograd.Function):
 
 class MappoUpdater:
     def __init__(self, net: MappoPolicy, ell: torch.Tensor, env_graph: torch.Tensor, lr: float = 3e-4, clip: float = 0.2,
-                 minibatch: int = 32768, value_coef: float = 0.5, use_graph: bool = False, mrx_money: int = 1000):
-        """ell int32 [G, N, 16] (the engine's board table: neighbour | weight << 16), env_graph int [B]."""
+                 minibatch: int = 32768, value_coef: float = 0.5, use_graph: bool = False, mrx_money: int = 1000,
+                 fused: Optional[bool] = None):
+        """ell int32 [G, N, 16] (the engine's board table: neighbour | weight << 16), env_graph int [B].
+        fused: None = the HIP gradient kernel when it applies (GPU, hidden a multiple of 4 up to 128);
+        True = require it (raises otherwise); False = the torch form."""
         self.net, self.clip, self.minibatch, self.value_coef = net, float(clip), int(minibatch), float(value_coef)
         self.device = next(net.parameters()).device
         self.ell = ell.to(self.device)
@@ -60,6 +71,128 @@ class MappoUpdater:
         self.use_graph = bool(use_graph) and on_gpu
         self._graph, self._static = None, None
         self.last_losses = None
+        self._fz = None
+        self._env_graph32 = self.env_graph.to(torch.int32).contiguous()
+        H = net.actors[0][0].out_features
+        fits = on_gpu and H % 4 == 0 and H <= 128
+        if fused and not fits:
+            raise ValueError("the fused PPO gradient kernel needs a GPU and hidden % 4 == 0, hidden <= 128")
+        self.fused = fits if fused is None else bool(fused)
+        self.H = H
+
+    @staticmethod
+    def _slab_floats(N, H):
+        """floats per role of the kernel's gradient layout (mirror of sy_ppo_slab_floats; checked against it in `_fused_state`)"""
+        return 2 * N * H + H + ((max(N, H) + 3) & ~3) + 8
+
+    # ------------------------------------------------------------------ the HIP gradient kernel
+    def _fused_state(self):
+        """Persistent buffers of the fused path (allocated once: a captured graph replays on them): the parameters in the
+        kernel's layouts, the gradient slab and — as views / small transposed copies of it — every parameter's .grad."""
+        if self._fz is not None:
+            return self._fz
+        from . import _lib
+        lib = _lib.load()
+        net, A, P, N, H, dev = self.net, self.A, self.P, self.N, self.H, self.device
+        S = int(lib.sy_ppo_slab_floats(N, H))
+        assert S == self._slab_floats(N, H)
+        f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)    # noqa: E731
+        z = {"lib": lib, "_lib": _lib, "S": S, "w1": f(A, H, N), "w1t": f(A, N, H), "w2": f(A, N, H), "b1": f(A, H), "b2": f(A, N),
+             "c1m": f(N, H), "c1p": f(N, H), "grads": f(A + 1, S), "gW1": f(A, H, N), "gC1": f(H, A, N),
+             "scratch": f(int(lib.sy_ppo_scratch_floats(A, N, H))), "rows": torch.zeros(max(self.minibatch, 1), dtype=torch.int32, device=dev),
+             "actor_loss": f(), "critic_loss": f()}
+        NH, g = N * H, z["grads"]
+        DN = (max(N, H) + 3) & ~3
+        oC, oD, oE = 2 * NH, 2 * NH + H, 2 * NH + H + DN
+        z["oE"] = oE
+        for a, actor in enumerate(net.actors):
+            actor[0].weight.grad = z["gW1"][a]
+            actor[0].bias.grad = g[a, oC:oC + H]
+            actor[2].weight.grad = g[a, NH:2 * NH].view(N, H)
+            actor[2].bias.grad = g[a, oD:oD + N]
+        net.critic[0].weight.grad = z["gC1"].view(H, A * N)
+        net.critic[0].bias.grad = g[A, oC:oC + H]
+        net.critic[2].weight.grad = g[A, oD:oD + H].view(1, H)
+        net.critic[2].bias.grad = g[A, oE + 1:oE + 2]
+        self._fz = z
+        return z
+
+    def _step_fused(self, z, src, num_rows):
+        """One minibatch: parameters -> kernel layouts, sy_mappo_ppo_grad, gradients -> torch layouts, Adam."""
+        net, A, P, N, H = self.net, self.A, self.P, self.N, self.H
+        NH = N * H
+        with torch.no_grad():
+            torch.stack([a[0].weight for a in net.actors], out=z["w1"])
+            z["w1t"].copy_(z["w1"].transpose(1, 2))
+            torch.stack([a[2].weight for a in net.actors], out=z["w2"])
+            torch.stack([a[0].bias for a in net.actors], out=z["b1"])
+            torch.stack([a[2].bias for a in net.actors], out=z["b2"])
+            c1 = net.critic[0].weight.view(H, A, N)
+            z["c1m"].copy_(c1[:, 0].t())
+            z["c1p"].copy_(c1[:, 1:].sum(1).t())
+            ptr = lambda t: C.c_void_p(t.data_ptr())                               # noqa: E731
+            args = z["_lib"].PpoArgs(ptr(src["record"]), int(src["record"].shape[-1]), ptr(src["log_prob"]), ptr(src["adv"]),
+                                     ptr(src["team_ret"]), ptr(z["rows"]), 0, int(num_rows), int(src["B"]), ptr(self.ell),
+                                     ptr(src["env_graph"]), P, N, H, ptr(z["w1t"]), ptr(z["b1"]), ptr(z["w2"]), ptr(z["b2"]),
+                                     ptr(z["c1m"]), ptr(z["c1p"]), ptr(net.critic[0].bias), ptr(net.critic[2].weight),
+                                     ptr(net.critic[2].bias), self.clip, self.value_coef, ptr(z["scratch"]),
+                                     int(z["scratch"].numel()), ptr(z["grads"]))
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            z["_lib"].check(z["lib"].sy_mappo_ppo_grad(C.byref(args), stream), "sy_mappo_ppo_grad")
+            g = z["grads"]
+            z["gW1"].copy_(g[:A, :NH].view(A, N, H).transpose(1, 2))
+            z["gC1"][:, 0].copy_(g[A, :NH].view(N, H).t())
+            z["gC1"][:, 1:].copy_(g[A, NH:2 * NH].view(N, H).t().unsqueeze(1).expand(H, P, N))
+            z["actor_loss"].copy_(g[:A, z["oE"]].sum())
+            z["critic_loss"].copy_(g[A, z["oE"]])
+        self.opt.step()
+
+    def _update_fused(self, rec, returns, values, generator):
+        T, B, A = rec["action"].shape
+        R = T * B
+        mb = min(self.minibatch, R)
+        record = rec["record"]
+        if record.dtype != torch.int32 or not record.is_contiguous() or record.shape[:2] != (T, B):
+            raise ValueError("the fused update reads the packed rollout record: rec['record'] must be the contiguous int32 [T, B, RW] tensor")
+        adv = returns if values is None else returns - values.unsqueeze(-1)
+        adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).float().contiguous()      # mappo_agent.py:256-258
+        src = {"record": record, "log_prob": rec["log_prob"].float().contiguous(), "adv": adv,
+               "team_ret": returns.sum(-1).float().contiguous(), "B": B,
+               "env_graph": self._env_graph32}
+        if self.ell.dtype != torch.int32 or not self.ell.is_contiguous():
+            self.ell = self.ell.to(torch.int32).contiguous()
+        z = self._fused_state()
+        if z["rows"].numel() < mb:
+            z["rows"] = torch.zeros(mb, dtype=torch.int32, device=self.device)
+            self._graph = None
+        perm = torch.randperm(R, device=self.device, generator=generator).to(torch.int32)
+        key = (record.data_ptr(), src["log_prob"].data_ptr(), mb)
+        if self.use_graph and self._graph is not None and self._graph_key[:3] != key:
+            self._graph = None                                                    # other buffers: capture again
+        for i in range(R // mb):                                                  # (a ragged tail is dropped, as minibatch PPO does)
+            z["rows"][:mb].copy_(perm[i * mb:(i + 1) * mb])
+            if not self.use_graph:
+                self._step_fused(z, src, mb)
+            elif self._graph is None:
+                # adv / team_ret are fresh tensors on every update: a captured graph reads them from persistent copies
+                z["adv_s"] = torch.empty_like(src["adv"])
+                z["ret_s"] = torch.empty_like(src["team_ret"])
+                z["adv_s"].copy_(src["adv"])
+                z["ret_s"].copy_(src["team_ret"])
+                gsrc = dict(src, adv=z["adv_s"], team_ret=z["ret_s"])
+                self._step_fused(z, gsrc, mb)                                     # first minibatch: eager (warm-up), then capture
+                torch.cuda.synchronize(self.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.device(self.device), torch.cuda.graph(g):
+                    self._step_fused(z, gsrc, mb)
+                self._graph, self._graph_key = g, key + (gsrc,)
+            else:
+                if i == 0:
+                    z["adv_s"].copy_(src["adv"])
+                    z["ret_s"].copy_(src["team_ret"])
+                self._graph.replay()
+        self.last_losses = (z["actor_loss"], z["critic_loss"])
+        return self.last_losses
 
     # ------------------------------------------------------------------ one minibatch
     def _losses(self, pos, budget, act, old_lp, adv, team_ret, graph_of_row):
@@ -119,6 +252,8 @@ class MappoUpdater:
         `env.alloc_rollout` record of a policy rollout); returns [T, B, A] (`collector.device_returns`); values [T, B]
         or None (advantage = standardised return).  Returns (actor_loss, critic_loss) of the last minibatch as device
         tensors — nothing here synchronises with the host."""
+        if self.fused and rec.get("record") is not None:
+            return self._update_fused(rec, returns, values, generator)
         T, B, A = rec["action"].shape
         R = T * B
         mb = min(self.minibatch, R)

@@ -1029,3 +1029,77 @@ def test_in_kernel_policy_underflow_rule_and_hidden_128(sy):
         env.close()
     with pytest.raises(ValueError):
         pol.DeviceMappoPolicy(pol.MappoPolicy(N, P, hidden_size=256).to("cuda"))
+
+
+@pytest.mark.parametrize("N,P,H,B,T", [(200, 4, 64, 96, 24), (60, 3, 32, 50, 16), (100, 6, 128, 40, 12), (24, 2, 8, 33, 20), (150, 7, 64, 21, 10),
+                                       (200, 4, 128, 48, 8)])      # (the last: a table larger than the LDS, two row ranges)
+def test_fused_ppo_gradient_matches_the_torch_form(sy, N, P, H, B, T):
+    """sy_mappo_ppo_grad (loss + gradient of a PPO minibatch in one HIP kernel, LDS-resident gradient tables) against the
+    torch restatement of MappoAgent.ppo_update (update.py::_losses + autograd) on a recorded policy rollout: both losses and
+    the gradient of EVERY parameter (actors' two layers, the critic's MrX / police blocks and head) to float32 rounding,
+    for one full-batch step and for several minibatches (the weights after Adam)."""
+    import copy
+    from student_mechanism_design_amd import collector as col, policies as pol
+    from student_mechanism_design_amd.update import MappoUpdater
+    boards = sy.sample_board_pool(3, N, int(1.8 * N), seed=N)
+    env = sy.BatchedScotlandYardEnv(B, boards, P, 9, np.linspace(0.2, 0.8, 11), seed=N + P, reveal_interval=3)
+    torch.manual_seed(N + H)
+    net_t = pol.MappoPolicy(N, P, hidden_size=H).to(env.device)
+    with torch.no_grad():
+        for a in net_t.actors:
+            a[2].bias.normal_(0.0, 1.0)
+    net_f = copy.deepcopy(net_t)
+    dev_pol = pol.DeviceMappoPolicy(net_t, seed=2)
+    env.set_policy(dev_pol)
+    rec = env.rollout(T)
+    ret, _ = col.device_returns(rec["reward"], rec["terminated"], 0.99, done_b=rec["truncated"])
+    R = T * B
+    up_t = MappoUpdater(net_t, env.ell, env.env_graph, minibatch=R, fused=False, lr=1e-3)
+    up_f = MappoUpdater(net_f, env.ell, env.env_graph, minibatch=R, fused=True, lr=1e-3)
+    assert up_f.fused and not up_t.fused
+    lt = [float(x) for x in up_t.update(rec, ret)]
+    lf = [float(x) for x in up_f.update(rec, ret)]
+    np.testing.assert_allclose(lf, lt, rtol=2e-5, atol=1e-7)
+    assert lt[1] > 0            # (the first step's actor loss is -mean(standardised advantage) = 0 up to rounding: ratio 1)
+    for (name, pt), (_, pf) in zip(net_t.named_parameters(), net_f.named_parameters()):
+        gt, gf = _np(pt.grad), _np(pf.grad)
+        scale = float(np.abs(gt).max())
+        assert scale > 0, name
+        np.testing.assert_allclose(gf, gt, rtol=1e-4, atol=2e-6 * scale, err_msg=name)
+        np.testing.assert_allclose(_np(pf), _np(pt), rtol=0, atol=2e-5, err_msg=name)       # after the Adam step
+    # minibatches (a different shuffle per path: compare what does not depend on it — finite losses, parameters that moved)
+    g = torch.Generator(device=env.device)
+    up_f2 = MappoUpdater(net_f, env.ell, env.env_graph, minibatch=max(R // 4, 1), fused=True, lr=1e-3)
+    before = [p.detach().clone() for p in net_f.parameters()]
+    al, cl = up_f2.update(rec, ret, generator=g.manual_seed(1))
+    assert np.isfinite(float(al)) and np.isfinite(float(cl))
+    assert all(bool((p != b).any()) for p, b in zip(net_f.parameters(), before))
+    env.close()
+
+
+def test_fused_ppo_update_replays_as_a_graph(sy):
+    """use_graph=True on the fused path: the minibatch step (pack, sy_mappo_ppo_grad, unpack, Adam) captured once and
+    replayed gives the same parameters as the eager path, update after update (same shuffles)."""
+    import copy
+    from student_mechanism_design_amd import collector as col, policies as pol
+    from student_mechanism_design_amd.update import MappoUpdater
+    N, P, H, B, T = 80, 4, 64, 64, 16
+    boards = sy.sample_board_pool(2, N, 150, seed=3)
+    env = sy.BatchedScotlandYardEnv(B, boards, P, 9, np.full(11, 0.5), seed=4, reveal_interval=3)
+    torch.manual_seed(5)
+    net_e = pol.MappoPolicy(N, P, hidden_size=H).to(env.device)
+    net_g = copy.deepcopy(net_e)
+    env.set_policy(pol.DeviceMappoPolicy(net_e, seed=2))
+    out = env.alloc_rollout(T)
+    up_e = MappoUpdater(net_e, env.ell, env.env_graph, minibatch=256, fused=True, use_graph=False)
+    up_g = MappoUpdater(net_g, env.ell, env.env_graph, minibatch=256, fused=True, use_graph=True)
+    gen = torch.Generator(device=env.device)
+    for it in range(3):
+        rec = env.rollout(T, out=out)
+        ret, _ = col.device_returns(rec["reward"], rec["terminated"], 0.99, done_b=rec["truncated"])
+        le = up_e.update(rec, ret, generator=gen.manual_seed(it))
+        lg = up_g.update(rec, ret, generator=gen.manual_seed(it))
+        np.testing.assert_allclose([float(x) for x in lg], [float(x) for x in le], rtol=1e-4, atol=1e-6)
+    for pe, pg in zip(net_e.parameters(), net_g.parameters()):
+        np.testing.assert_allclose(_np(pg), _np(pe), rtol=0, atol=1e-5)
+    env.close()

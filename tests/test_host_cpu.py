@@ -87,10 +87,10 @@ def test_reward_tables_are_the_reference_formulas():
 
 
 def test_capi_library_exports_every_declared_symbol():
-    """include/sy_env.h is the contract: every `int sy_*(`/`const char *sy_*(` must be exported."""
+    """include/sy_env.h is the contract: every `int sy_*(` / `int32_t|int64_t sy_*(` / `const char *sy_*(` must be exported."""
     with open(os.path.join(ROOT, "include", "sy_env.h")) as f:
         header = f.read()
-    declared = set(re.findall(r"^(?:int|const char \*)\s*(sy_[a-z_0-9]+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int32_t|int64_t|const char \*)\s*(sy_[a-z_0-9]+)\s*\(", header, flags=re.M))
     assert declared == set(sy._lib.EXPORTS), declared ^ set(sy._lib.EXPORTS)
     assert os.path.exists(sy.LIB_PATH), "build the engine first: python -m student_mechanism_design_amd.build"
     lib = C.CDLL(sy.LIB_PATH)

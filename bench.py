@@ -174,9 +174,10 @@ def config3_record(args, boards, weights, device):
     med = lambda k: float(np.median([p_[k] for p_ in parts]))   # noqa: E731
     n = T * B * A
     rec3 = {"what": "BASELINE configs[2]: learned policy (MAPPO actors, hidden 64) sampling inside the fused rollout, T=64 x "
-                    "%d envs, returns in one HIP launch, one minibatch-PPO pass (minibatch 32768 env-steps%s), weights "
-                    "refreshed; medians of %d iterations" % (B, ", each step one HIP graph" if up.use_graph else "", iters),
-            "kernel": env.rollout_kernel_name(), "agent_transitions_per_iteration": n,
+                    "%d envs, returns in one HIP launch, one minibatch-PPO pass (minibatch 32768 env-steps: %s%s), weights "
+                    "refreshed; medians of %d iterations" % (B, "loss + gradient in one HIP kernel, sy_mappo_ppo_grad, then fused Adam"
+                                                             if up.fused else "torch autograd", ", each step one HIP graph" if up.use_graph else "", iters),
+            "kernel": env.rollout_kernel_name(), "update_path": "sy_mappo_ppo_grad" if up.fused else "torch", "agent_transitions_per_iteration": n,
             "collect_ms": med("collect"), "returns_ms": med("returns"), "update_ms": med("update"),
             "collect_agent_steps_per_s": n / (med("collect") * 1e-3),
             "iteration_ms_unsplit": whole_ms / iters, "iteration_agent_steps_per_s": n * iters / (whole_ms * 1e-3),

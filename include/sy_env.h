@@ -286,32 +286,54 @@ typedef struct sy_returns_args {
 } sy_returns_args;
 int sy_returns_advantages(const sy_returns_args *args, void *stream);
 
-/* replaces the loss + backward of MappoAgent.ppo_update (agent/mappo_agent.py:260-293) for one minibatch of a rollout
- * record, in one launch (+ a reduction launch): the clipped surrogate (epsilon `clip`) of every agent's recorded action
- * under its actor — the masked, renormalised softmax of select_action (mappo_agent.py:112-134) over the affordable
- * entries of the agent's ELL row — averaged over num_rows * A, plus value_coef * the central critic's MSE against
- * `team_ret`, and the gradient of that sum with respect to every parameter.  All pointers device.
+/* replaces the loss + backward of MappoAgent.ppo_update (agent/mappo_agent.py:260-293) over a rollout record, minibatch
+ * by minibatch: the clipped surrogate (epsilon `clip`) of every agent's recorded action under its actor — the masked,
+ * renormalised softmax of select_action (mappo_agent.py:112-134) over the affordable entries of the agent's ELL row —
+ * averaged over num_rows * A, plus value_coef * the central critic's MSE against the team return, and the gradient of
+ * that sum with respect to every parameter.  All pointers device.  Two entry points:
+ *
+ * sy_ppo_pack — once per update: the (shuffled) rows of the record into a compact IMAGE the gradient launches stream
+ * (sy_ppo_image_bytes(A, num_rows) bytes: 16 B of agent nodes + 16 B per agent + 8 B per row).
  *   record   [R][record_words] packed rollout rows (sy_rollout_buffers.record): pos, budget, action are read in place
  *   log_prob [R][A] recorded log-probabilities, adv [R][A] (standardised) advantages, team_ret [R] critic targets
- *   rows     [num_rows] int32 row indices of the minibatch, or NULL = rows row0 .. row0 + num_rows - 1;
- *            row r belongs to env r % num_envs (records are [T][B]); env_graph [num_envs], ell uint32 [G][N][16]
- *   w1t [A][N][H], b1 [A][H], w2 [A][N][H] (torch's layout), b2 [A][N]: the actors;  critic: c1m [N][H] = first layer's
- *   MrX block transposed, c1p [N][H] = the SUM of its P police blocks transposed (the critic's input repeats the police
- *   multi-hot P times, mappo_trainer.py:197-208), cb1 [H], c2 [H], cb2 [1]
+ *   rows     [num_rows] int32 record rows in image order (a permutation of the record, or part of one), or NULL =
+ *            rows row0 .. row0 + num_rows - 1; record row r belongs to env r % num_envs (records are [T][B]);
+ *            env_graph [num_envs] the board of every env
+ *
+ * sy_mappo_ppo_grad — once per minibatch = image rows row0 .. row0 + num_rows - 1 (row0_dev != NULL: row0 is read from
+ * that device word instead, so that one captured graph serves every minibatch), one launch + a reduction launch:
+ *   ell uint32 [G][N][16];  w1t [A][N][H], b1 [A][H], w2 [A][N][H] (torch's layout), b2 [A][N]: the actors;  critic: c1m
+ *   [N][H] = first layer's MrX block transposed, c1p [N][H] = the SUM of its P police blocks transposed (the critic's input
+ *   repeats the police multi-hot P times, mappo_trainer.py:197-208), cb1 [H], c2 [H], cb2 [1]
  *   grads [A + 1][S], S = sy_ppo_slab_floats(N, H): role a < A = actor a: d w1t[a] (N*H) | d w2[a] (N*H) | d b1[a] (H) |
  *   d b2[a] (N, padded to DN = max(N, H) rounded up to 4) | 8 floats: [0] = actor a's share of the actor loss;
  *   role A = critic: d c1m | d c1p (the gradient of EACH police block) | d cb1 | d c2 (H, padded to DN) | [0] = critic
  *   loss (MSE, without value_coef), [1] = d cb2.   scratch: sy_ppo_scratch_floats(A, N, H) floats.
- * Limits: hidden a multiple of 4, at most 128.  Sums are accumulated in float64 (LDS), in a different order than a BLAS
- * matmul: parity with the torch form is to float32 rounding. */
-typedef struct sy_ppo_args {
+ * Limits: hidden a multiple of 4, at most 128; nodes < 65 536.  Sums are accumulated in float64 (LDS), in a different
+ * order than a BLAS matmul: parity with the torch form is to float32 rounding. */
+typedef struct sy_ppo_pack_args {
     const int32_t *record;
     int32_t record_words;
     const float *log_prob, *adv, *team_ret;
     const int32_t *rows;
-    int32_t row0, num_rows, num_envs;
-    const uint32_t *ell;
+    int32_t row0;
+    int64_t num_rows;
+    int32_t num_envs;
     const int32_t *env_graph;
+    int32_t num_police;
+    void *image;
+    int64_t image_bytes;
+} sy_ppo_pack_args;
+int64_t sy_ppo_image_bytes(int32_t num_agents, int64_t num_rows);
+int sy_ppo_pack(const sy_ppo_pack_args *args, void *stream);
+
+typedef struct sy_ppo_args {
+    const void *image;
+    int64_t image_rows;       /* rows the image was packed with */
+    int32_t row0;
+    const int32_t *row0_dev;
+    int32_t num_rows;
+    const uint32_t *ell;
     int32_t num_police, num_nodes, hidden;
     const float *w1t, *b1, *w2, *b2;
     const float *c1m, *c1p, *cb1, *c2, *cb2;

@@ -48,11 +48,17 @@ class ReturnsArgs(C.Structure):
                 ("adv", C.c_void_p)]
 
 
-class PpoArgs(C.Structure):
+class PpoPackArgs(C.Structure):
     _fields_ = [("record", C.c_void_p), ("record_words", C.c_int32), ("log_prob", C.c_void_p), ("adv", C.c_void_p),
-                ("team_ret", C.c_void_p), ("rows", C.c_void_p), ("row0", C.c_int32), ("num_rows", C.c_int32),
-                ("num_envs", C.c_int32), ("ell", C.c_void_p), ("env_graph", C.c_void_p), ("num_police", C.c_int32),
-                ("num_nodes", C.c_int32), ("hidden", C.c_int32), ("w1t", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p),
+                ("team_ret", C.c_void_p), ("rows", C.c_void_p), ("row0", C.c_int32), ("num_rows", C.c_int64),
+                ("num_envs", C.c_int32), ("env_graph", C.c_void_p), ("num_police", C.c_int32), ("image", C.c_void_p),
+                ("image_bytes", C.c_int64)]
+
+
+class PpoArgs(C.Structure):
+    _fields_ = [("image", C.c_void_p), ("image_rows", C.c_int64), ("row0", C.c_int32), ("row0_dev", C.c_void_p),
+                ("num_rows", C.c_int32), ("ell", C.c_void_p), ("num_police", C.c_int32), ("num_nodes", C.c_int32),
+                ("hidden", C.c_int32), ("w1t", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p),
                 ("b2", C.c_void_p), ("c1m", C.c_void_p), ("c1p", C.c_void_p), ("cb1", C.c_void_p), ("c2", C.c_void_p),
                 ("cb2", C.c_void_p), ("clip", C.c_float), ("value_coef", C.c_float), ("scratch", C.c_void_p),
                 ("scratch_floats", C.c_int64), ("grads", C.c_void_p)]
@@ -68,7 +74,7 @@ EXPORTS = ["sy_abi_version", "sy_record_words", "sy_last_error", "sy_env_create"
            "sy_masked_categorical_sample", "sy_mappo_policy_act", "sy_env_bind_status", "sy_env_status",
            "sy_returns_advantages", "sy_build_id", "sy_env_rollout_kernel_name",
            "sy_gnn_padded_features", "sy_gnn_param_floats", "sy_gnn_q_act",
-           "sy_ppo_slab_floats", "sy_ppo_scratch_floats", "sy_mappo_ppo_grad"]
+           "sy_ppo_slab_floats", "sy_ppo_scratch_floats", "sy_mappo_ppo_grad", "sy_ppo_image_bytes", "sy_ppo_pack"]
 
 _lib = None
 
@@ -117,11 +123,14 @@ def load():
     lib.sy_ppo_slab_floats.argtypes = [i32, i32]
     lib.sy_ppo_scratch_floats.argtypes = [i32, i32, i32]
     lib.sy_mappo_ppo_grad.argtypes = [C.POINTER(PpoArgs), vp]
+    lib.sy_ppo_image_bytes.argtypes = [i32, C.c_int64]
+    lib.sy_ppo_pack.argtypes = [C.POINTER(PpoPackArgs), vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("sy_last_error", "sy_build_id"):
             fn.restype = C.c_int
     lib.sy_ppo_scratch_floats.restype = C.c_int64
+    lib.sy_ppo_image_bytes.restype = C.c_int64
     if lib.sy_abi_version() != ABI_VERSION:
         raise EngineError(f"libsy_env.so ABI {lib.sy_abi_version()} != expected {ABI_VERSION}; rebuild it")
     _lib = lib

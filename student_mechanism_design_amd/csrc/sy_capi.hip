@@ -418,26 +418,46 @@ int64_t sy_ppo_scratch_floats(int32_t num_agents, int32_t num_nodes, int32_t hid
     return (int64_t)sy::ppo_blocks_per_role(num_agents, num_nodes, hidden) * (num_agents + 1) * sy::ppo_slab_floats(num_nodes, hidden);
 }
 
+int64_t sy_ppo_image_bytes(int32_t num_agents, int64_t num_rows) {
+    return num_agents < 1 || num_rows < 0 ? 0 : (int64_t)sy::ppo_image_size(num_agents, num_rows);
+}
+
+int sy_ppo_pack(const sy_ppo_pack_args* a, void* stream) {
+    if (!a || !a->record || !a->log_prob || !a->adv || !a->team_ret || !a->env_graph || !a->image)
+        return fail(SY_ERR_INVALID, "sy_ppo_pack: null argument%s");
+    const int A = a->num_police + 1;
+    if (a->num_police < 1 || A > SY_MAX_AGENTS || a->num_rows < 1 || a->num_envs < 1 || a->row0 < 0)
+        return fail(SY_ERR_INVALID, "sy_ppo_pack: bad sizes%s");
+    if (a->record_words < sy_record_words(A)) return fail(SY_ERR_INVALID, "sy_ppo_pack: record_words too small for this many agents%s");
+    if (a->image_bytes < sy_ppo_image_bytes(A, a->num_rows)) return fail(SY_ERR_INVALID, "sy_ppo_pack: image too small%s");
+    if (reinterpret_cast<uintptr_t>(a->image) & 15) return fail(SY_ERR_INVALID, "sy_ppo_pack: image must be 16-byte aligned%s");
+    sy::PpoPackArgs k;
+    k.record = a->record; k.RW = a->record_words; k.log_prob = a->log_prob; k.adv = a->adv; k.team_ret = a->team_ret;
+    k.rows = a->rows; k.row0 = a->row0; k.count = a->num_rows; k.B = a->num_envs; k.env_graph = a->env_graph; k.A = A;
+    k.image = a->image;
+    hipError_t e = sy::launch_ppo_pack(k, (hipStream_t)stream);
+    return e == hipSuccess ? SY_OK : hip_fail(e, "sy_ppo_pack launch");
+}
+
 int sy_mappo_ppo_grad(const sy_ppo_args* a, void* stream) {
-    if (!a || !a->record || !a->log_prob || !a->adv || !a->team_ret || !a->ell || !a->env_graph || !a->w1t || !a->b1 || !a->w2 ||
-        !a->b2 || !a->c1m || !a->c1p || !a->cb1 || !a->c2 || !a->cb2 || !a->scratch || !a->grads)
+    if (!a || !a->image || !a->ell || !a->w1t || !a->b1 || !a->w2 || !a->b2 || !a->c1m || !a->c1p || !a->cb1 || !a->c2 || !a->cb2 ||
+        !a->scratch || !a->grads)
         return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: null argument%s");
     const int A = a->num_police + 1;
-    if (a->num_police < 1 || A > SY_MAX_AGENTS || a->num_nodes < 2 || a->num_nodes > SY_MAX_NODES || a->num_rows < 1 ||
-        a->num_envs < 1 || a->row0 < 0)
+    if (a->num_police < 1 || A > SY_MAX_AGENTS || a->num_nodes < 2 || a->num_nodes > SY_MAX_NODES || a->num_rows < 1 || a->row0 < 0 ||
+        a->image_rows < 1)
         return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: bad sizes%s");
-    if (a->record_words < sy_record_words(A)) return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: record_words too small for this many agents%s");
+    if (!a->row0_dev && (int64_t)a->row0 + a->num_rows > a->image_rows) return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: the minibatch ends past the image%s");
     if (a->hidden < 4 || (a->hidden & 3) || a->hidden > 128) return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: hidden must be a multiple of 4 in [4, 128]%s");
     if (sy::ppo_parts(a->num_nodes, a->hidden) < 1) return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: no LDS for a gradient table row%s");
     if (a->scratch_floats < sy_ppo_scratch_floats(A, a->num_nodes, a->hidden)) return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: scratch too small%s");
     const uintptr_t al = reinterpret_cast<uintptr_t>(a->w1t) | reinterpret_cast<uintptr_t>(a->w2) | reinterpret_cast<uintptr_t>(a->b1) |
                          reinterpret_cast<uintptr_t>(a->c1m) | reinterpret_cast<uintptr_t>(a->c1p) | reinterpret_cast<uintptr_t>(a->cb1) |
-                         reinterpret_cast<uintptr_t>(a->c2);
-    if (al & 15) return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: parameter tables must be 16-byte aligned%s");
+                         reinterpret_cast<uintptr_t>(a->c2) | reinterpret_cast<uintptr_t>(a->image);
+    if (al & 15) return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: parameter tables and the image must be 16-byte aligned%s");
     sy::PpoArgs k;
-    k.record = a->record; k.RW = a->record_words; k.log_prob = a->log_prob; k.adv = a->adv; k.team_ret = a->team_ret;
-    k.rows = a->rows; k.row0 = a->row0; k.mb = a->num_rows; k.B = a->num_envs;
-    k.ell = a->ell; k.env_graph = a->env_graph; k.A = A; k.N = a->num_nodes; k.H = a->hidden;
+    k.image = a->image; k.image_rows = a->image_rows; k.row0 = a->row0; k.row0_dev = a->row0_dev; k.mb = a->num_rows;
+    k.ell = a->ell; k.A = A; k.N = a->num_nodes; k.H = a->hidden;
     k.w1t = a->w1t; k.b1 = a->b1; k.w2 = a->w2; k.b2 = a->b2;
     k.c1m = a->c1m; k.c1p = a->c1p; k.cb1 = a->cb1; k.c2 = a->c2; k.cb2 = a->cb2;
     k.clip = a->clip; k.value_coef = a->value_coef; k.partial = a->scratch; k.DN = 0; k.slab = 0; k.parts = 0; k.rpp = 0;

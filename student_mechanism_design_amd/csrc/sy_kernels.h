@@ -116,17 +116,26 @@ hipError_t launch_mappo_policy(const int32_t* pos, const uint8_t* mask, long lon
                                hipStream_t stream);
 
 // one PPO minibatch of the MAPPO networks: loss + gradient (sy_ppo.hip, sy_mappo_ppo_grad)
-struct PpoArgs {
+struct PpoPackArgs {     // rows of a rollout record -> the minibatch image (sy_ppo_pack)
     const int32_t* record; int32_t RW;
     const float* log_prob; const float* adv; const float* team_ret;
-    const int32_t* rows; int32_t row0, mb, B;
-    const uint32_t* ell; const int32_t* env_graph;
+    const int32_t* rows; int32_t row0; long long count; int32_t B;
+    const int32_t* env_graph;
+    int32_t A;
+    void* image;
+};
+struct PpoArgs {
+    const void* image; long long image_rows;       // the packed rows of an update (sy_ppo_pack)
+    int32_t row0; const int32_t* row0_dev; int32_t mb;   // this minibatch: image rows row0 .. row0 + mb - 1
+    const uint32_t* ell;
     int32_t A, N, H;
     const float *w1t, *b1, *w2, *b2, *c1m, *c1p, *cb1, *c2, *cb2;
     float clip, value_coef;
     float* partial;
     int32_t DN, slab, parts, rpp;     // filled by the launcher (parts: row ranges a table is cut into; rpp: rows per part)
 };
+size_t ppo_image_size(int A, long long rows);
+hipError_t launch_ppo_pack(const PpoPackArgs& a, hipStream_t stream);
 int ppo_slab_floats(int N, int H);
 int ppo_parts(int N, int H);
 int ppo_blocks_per_role(int A, int N, int H);

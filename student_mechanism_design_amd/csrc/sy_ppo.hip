@@ -71,40 +71,73 @@ __device__ __forceinline__ ppo_f4 gate4(ppo_f4 z, ppo_f4 d) {    // d where z > 
     return o;
 }
 
-// What a group needs of its row before any table lookup: prefetched one iteration ahead (two dependent loads — the
-// minibatch's row index, then the record words — that would otherwise head every iteration's chain of loads).
+// What a group needs of its row before any table lookup, read from the minibatch IMAGE (ppo_pack_kernel below): the
+// shuffled rows of an update, packed once — 16 bytes of agent nodes, 16 bytes per (row, agent), 8 bytes of critic target +
+// board — so that the 2 (A + 1) roles stream consecutive rows instead of each gathering ~5 scattered 128-byte lines per row
+// from a record larger than the L2s (250 MB of random reads per 32 768-row launch: a 50 us floor under the first version).
 struct PpoRow {
-    int r;          // record row
     int posv;       // lane j < A: node of agent j before the step
     int bud, act;   // the actor's agent: budget before the step, recorded action
     float olp, adv; // recorded log-probability, advantage           (critic: adv = the team return)
     int g;          // board of the row's env
     bool on;        // the group has a row (the tail of a minibatch may not fill all four groups)
 };
+struct PpoImage {
+    const uint16_t* posq;   // [rows][8] agent nodes
+    const int4* agent;      // [A][rows] {budget, action, log-prob bits, advantage bits}
+    const int2* tail;       // [rows] {team return bits, board}
+};
+__host__ __device__ inline size_t ppo_image_bytes(int A, long long rows) { return (size_t)rows * (16 + 16 * (size_t)A + 8); }
+__host__ __device__ inline PpoImage ppo_image(const void* base, int A, long long rows) {
+    PpoImage im;
+    const char* b = reinterpret_cast<const char*>(base);
+    im.posq = reinterpret_cast<const uint16_t*>(b);
+    im.agent = reinterpret_cast<const int4*>(b + (size_t)rows * 16);
+    im.tail = reinterpret_cast<const int2*>(b + (size_t)rows * (16 + 16 * (size_t)A));
+    return im;
+}
 template <bool ACTOR>
-__device__ __forceinline__ PpoRow ppo_fetch_row(const PpoArgs& p, int i, int a, int j) {
+__device__ __forceinline__ PpoRow ppo_fetch_row(const PpoArgs& p, const PpoImage& im, int row0, int i, int a, int j) {
     PpoRow w;
     w.on = i < p.mb;
-    const int ii = w.on ? i : p.mb - 1;
-    w.r = p.rows ? p.rows[ii] : p.row0 + ii;
-    const int A = p.A;
-    const int32_t* const rec = p.record + (size_t)w.r * p.RW;
-    w.posv = j < A ? rec[2 * A + j] : 0;
+    const size_t r = (size_t)row0 + (size_t)(w.on ? i : p.mb - 1);
+    w.posv = (int)im.posq[r * 8 + (j & 7)];
+    const int2 t = im.tail[r];
     if (ACTOR) {
-        w.bud = rec[3 * A + a];
-        w.act = rec[4 * A + a];
-        w.olp = p.log_prob[(size_t)w.r * A + a];
-        w.adv = p.adv[(size_t)w.r * A + a];
-        w.g = p.env_graph[w.r % p.B];
+        const int4 q = im.agent[(size_t)a * p.image_rows + r];
+        w.bud = q.x; w.act = q.y; w.olp = __int_as_float(q.z); w.adv = __int_as_float(q.w);
     } else {
-        w.bud = 0; w.act = 0; w.olp = 0.0f; w.g = 0;
-        w.adv = p.team_ret[w.r];
+        w.bud = 0; w.act = 0; w.olp = 0.0f;
+        w.adv = __int_as_float(t.x);
     }
+    w.g = t.y;
     return w;
 }
 
-template <int KP, int KEEP>   // KP: 16-byte pieces of a hidden vector per lane, 1 (hidden <= 64) or 2 (<= 128);
-                              // KEEP: rounds of four W2 rows kept in registers for the backward pass
+// Pack the rows of an update: image row i <- record row rows[i] (rows == nullptr: row0 + i).
+__global__ __launch_bounds__(256) void ppo_pack_kernel(const PpoPackArgs p) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.count) return;
+    const int A = p.A;
+    const long long r = p.rows ? (long long)p.rows[i] : (long long)p.row0 + i;
+    const int32_t* const rec = p.record + (size_t)r * p.RW;
+    char* const base = reinterpret_cast<char*>(p.image);
+    uint16_t* const posq = reinterpret_cast<uint16_t*>(base) + (size_t)i * 8;
+    int4* const agent = reinterpret_cast<int4*>(base + (size_t)p.count * 16);
+    int2* const tail = reinterpret_cast<int2*>(base + (size_t)p.count * (16 + 16 * (size_t)A));
+    uint16_t q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) q[k] = k < A ? (uint16_t)rec[2 * A + k] : (uint16_t)0;
+    *reinterpret_cast<uint4*>(posq) = *reinterpret_cast<const uint4*>(q);
+    for (int k = 0; k < A; ++k)
+        agent[(size_t)k * p.count + i] = make_int4(rec[3 * A + k], rec[4 * A + k], __float_as_int(p.log_prob[(size_t)r * A + k]),
+                                                   __float_as_int(p.adv[(size_t)r * A + k]));
+    tail[i] = make_int2(__float_as_int(p.team_ret[r]), p.env_graph[r % p.B]);
+}
+
+template <int KP, int KEEP, bool WL>   // KP: 16-byte pieces of a hidden vector per lane, 1 (hidden <= 64) or 2 (<= 128);
+                                       // KEEP: rounds of four W2 rows kept in registers for the backward pass;
+                                       // WL: the network's second-layer table (critic: its police block) is staged in LDS
 __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
     extern __shared__ double acc[];
     const int N = p.N, H = p.H, NH = N * H, A = p.A, P = A - 1;
@@ -117,11 +150,18 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
     double* const gC = acc + (size_t)p.rpp * H;          // [H]   d b1[a] (table 0, part 0)            critic: d cb1
     double* const gD = gC + H;                           // [DN]  d b2[a] ([N]; table 1, part 0)       critic: d c2 ([H]; table 0, part 0)
     double* const gE = gD + p.DN;                        // [8]   0: loss sum (actor: table 1 part 0; critic: table 0 part 0), 1: d cb2
+    // WL: W2[a] (critic: c1p) as float32 [N][H] behind the sums.  Every row of the minibatch reads 4-8 rows of it: from L2
+    // that is most of the kernel's 1.4 GB of L1 <- L2 traffic per 32 768-row launch (11 TB/s: the kernel's bound before).
+    float* const wl = reinterpret_cast<float*>(gE + 8);
     const bool smalls = part == 0 && tab == (role < A ? 1 : 0);   // this block also owns the loss (+ b2 / critic head) sums
     const bool own_b1 = part == 0 && tab == 0;                    // ... the first layer's bias sums
     {
         const int tot = p.rpp * H + H + p.DN + 8;
         for (int k = threadIdx.x; k < tot; k += blockDim.x) acc[k] = 0.0;
+        if (WL) {
+            const ppo_f4* const src = reinterpret_cast<const ppo_f4*>(role < A ? p.w2 + (size_t)role * NH : p.c1p);
+            for (int k = threadIdx.x; k < (NH >> 2); k += blockDim.x) reinterpret_cast<ppo_f4*>(wl)[k] = src[k];
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
@@ -137,14 +177,20 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
     const ppo_f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     const int stride = gridDim.x * W * 4;
     int i = (blockIdx.x * W + wave) * 4 + u;
+    const PpoImage im = ppo_image(p.image, A, p.image_rows);
+    const int row0 = p.row0_dev ? *p.row0_dev : p.row0;        // (a device word: a captured graph replays on every minibatch)
     float loss = 0.0f;
     if (role < A) {
         // ---------------------------------------------------------------- actor `role`
         const int a = role;
         const float* const w1 = p.w1t + (size_t)a * NH;
-        const float* const w2 = p.w2 + (size_t)a * NH;
+        const float* const w2 = WL ? wl : p.w2 + (size_t)a * NH;
         const float* const b2 = p.b2 + (size_t)a * N;
+#ifdef SY_PPO_DIAG_NOZ
+        const int nit = 0;
+#else
         const int nit = a == 0 ? 1 : P;                      // nodes of the observation: MrX's / all police
+#endif
         const float inv = 1.0f / ((float)p.mb * (float)A);
         const float lo = 1.0f - p.clip, hi = 1.0f + p.clip;
         ppo_f4 b1p[KP], gb1[KP];
@@ -153,10 +199,9 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
             b1p[m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(p.b1 + (size_t)a * H + pk[m]) : zero4;
             gb1[m] = zero4;
         }
-        PpoRow nx = ppo_fetch_row<true>(p, i, a, j);
+        PpoRow nx = ppo_fetch_row<true>(p, im, row0, i, a, j);
         for (; __builtin_amdgcn_readfirstlane(i - u) < p.mb; i += stride) {
             const PpoRow rw = nx;
-            nx = ppo_fetch_row<true>(p, i + stride, a, j);
             const int node_a = __shfl(rw.posv, a, 16);
             // the agent's ELL row: lane j holds entry j; affordable entries compacted to lanes 0 .. n - 1 of the group
             const uint32_t ent = p.ell[((size_t)rw.g * N + node_a) * SY_ELL_WIDTH + j];
@@ -179,7 +224,15 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
             const int dstl = legal ? below : n + (j - below);                  // a permutation of the group's lanes
             const uint32_t cent = (uint32_t)__builtin_amdgcn_ds_permute((16 * u + dstl) << 2, (int)ent);
             const int nbj = (int)(cent & 0xffffu);                               // lane j < n: node of affordable entry j
+            const float b2j = j < n ? b2[nbj] : 0.0f;                            // (requested now, needed after the logits)
+            // the next row's words, requested LAST: loads return in order, so a wait for anything requested after them
+            // would wait for them too
+            nx = ppo_fetch_row<true>(p, im, row0, i + stride, a, j);
+#ifdef SY_PPO_DIAG_NOLOGIT
+            const int nmax = 0;
+#else
             const int nmax = __builtin_amdgcn_readfirstlane(max(max(__shfl(n, 0), __shfl(n, 16)), max(__shfl(n, 32), __shfl(n, 48))));
+#endif
             // logits: entry e of every group per step, four steps' rows in flight; lane j keeps the logit of entry j
             ppo_f4 wk[KEEP > 0 ? KEEP : 1][4][KP];
             float lgj = -3.0e38f;
@@ -215,7 +268,7 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
                 }
             }
             const bool mine = j < n;
-            if (mine) lgj += b2[nbj];
+            if (mine) lgj += b2j;
             const float mx = row16_max(mine ? lgj : -3.0e38f);
             const float ex = mine ? expf(lgj - mx) : 0.0f;
             const float se = row16_sum(ex);
@@ -313,20 +366,20 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
         }
         const float cb2 = p.cb2[0];
         float gcb2 = 0.0f;
-        PpoRow nx = ppo_fetch_row<false>(p, i, 0, j);
+        PpoRow nx = ppo_fetch_row<false>(p, im, row0, i, 0, j);
         for (; __builtin_amdgcn_readfirstlane(i - u) < p.mb; i += stride) {
             const PpoRow rw = nx;
-            nx = ppo_fetch_row<false>(p, i + stride, 0, j);
             ppo_f4 z[KP], hc[KP];
 #pragma unroll
             for (int m = 0; m < KP; ++m) z[m] = cb1p[m];
             for (int it = 0; it < A; ++it) {                         // item 0: MrX's node on c1m; items 1..P: police nodes on c1p
                 const int node = __shfl(rw.posv, it, 16);
-                const float* const tab = it == 0 ? p.c1m : p.c1p;
+                const float* const tab = it == 0 ? p.c1m : (WL ? wl : p.c1p);
 #pragma unroll
                 for (int m = 0; m < KP; ++m)
                     if (pv[m]) z[m] += *reinterpret_cast<const ppo_f4*>(tab + (size_t)node * H + pk[m]);
             }
+            nx = ppo_fetch_row<false>(p, im, row0, i + stride, 0, j);      // (after this iteration's lookups: see the actors)
             float d = 0.0f;
 #pragma unroll
             for (int m = 0; m < KP; ++m) {
@@ -402,22 +455,36 @@ int ppo_slab_floats(int N, int H) {
     const int dn = ((N > H ? N : H) + 3) & ~3;
     return 2 * N * H + H + dn + 8;
 }
-// rows of one [N][H] float64 table a block can hold beside the small vectors (one block per CU: 160 KB of LDS)
-static int ppo_rows_per_part(int N, int H) {
+// rows of one [N][H] float64 table a block can hold beside the small vectors (one block per CU: 160 KB of LDS), with
+// (`staged`) or without the float32 copy of the network's second-layer table
+static int ppo_rows_per_part(int N, int H, bool staged) {
     const int dn = ((N > H ? N : H) + 3) & ~3;
-    const long long room = 160 * 1024 - (long long)(H + dn + 8) * 8;
+    long long room = 160 * 1024 - (long long)(H + dn + 8) * 8 - (staged ? (long long)N * H * 4 : 0);
+    if (room < 0) room = 0;
     long long rpp = room / ((long long)H * 8);
     if (rpp > N) rpp = N;
     return (int)rpp;
 }
 int ppo_parts(int N, int H) {
-    const int rpp = ppo_rows_per_part(N, H);
+    const int rpp = ppo_rows_per_part(N, H, false);
     return rpp < 1 ? 0 : (N + rpp - 1) / rpp;
+}
+// stage the weights when that does not cut the gradient table into more row ranges
+static bool ppo_staged(int N, int H) {
+    const int rpp = ppo_rows_per_part(N, H, true);
+    return rpp >= 1 && (N + rpp - 1) / rpp == ppo_parts(N, H);
 }
 int ppo_blocks_per_role(int A, int N, int H) {
     const int parts = ppo_parts(N, H);
     const int nb = 256 / (2 * (A + 1) * (parts < 1 ? 1 : parts));    // one 1024-thread block per CU: 256 CUs
     return nb < 1 ? 1 : nb;
+}
+
+size_t ppo_image_size(int A, long long rows) { return ppo_image_bytes(A, rows); }
+
+hipError_t launch_ppo_pack(const PpoPackArgs& a, hipStream_t stream) {
+    hipLaunchKernelGGL(ppo_pack_kernel, dim3((unsigned)((a.count + 255) / 256)), dim3(256), 0, stream, a);
+    return hipGetLastError();
 }
 
 hipError_t launch_ppo_grad(PpoArgs a, float* grads, hipStream_t stream) {
@@ -426,13 +493,19 @@ hipError_t launch_ppo_grad(PpoArgs a, float* grads, hipStream_t stream) {
     a.parts = ppo_parts(a.N, a.H);
     if (a.parts < 1) return hipErrorInvalidValue;
     a.rpp = (a.N + a.parts - 1) / a.parts;           // balanced parts
+    const bool staged = ppo_staged(a.N, a.H);
     int nb = ppo_blocks_per_role(a.A, a.N, a.H);
     const int need = (a.mb + 63) / 64;          // a 16-wave block takes 64 rows per pass
     if (nb > need) nb = need;
-    const size_t lds = ((size_t)a.rpp * a.H + a.H + a.DN + 8) * sizeof(double);
+    const size_t lds = ((size_t)a.rpp * a.H + a.H + a.DN + 8) * sizeof(double) + (staged ? (size_t)a.N * a.H * sizeof(float) : 0);
     const dim3 grid(nb, 2 * (a.A + 1) * a.parts);
-    if (a.H <= 64) hipLaunchKernelGGL((ppo_grad_kernel<1, 2>), grid, dim3(1024), lds, stream, a);
-    else hipLaunchKernelGGL((ppo_grad_kernel<2, 0>), grid, dim3(1024), lds, stream, a);
+    if (a.H <= 64) {
+        if (staged) hipLaunchKernelGGL((ppo_grad_kernel<1, 0, true>), grid, dim3(1024), lds, stream, a);
+        else hipLaunchKernelGGL((ppo_grad_kernel<1, 2, false>), grid, dim3(1024), lds, stream, a);
+    } else {
+        if (staged) hipLaunchKernelGGL((ppo_grad_kernel<2, 0, true>), grid, dim3(1024), lds, stream, a);
+        else hipLaunchKernelGGL((ppo_grad_kernel<2, 0, false>), grid, dim3(1024), lds, stream, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int total = (a.A + 1) * a.slab;

@@ -99,8 +99,7 @@ class MappoUpdater:
         f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)    # noqa: E731
         z = {"lib": lib, "_lib": _lib, "S": S, "w1": f(A, H, N), "w1t": f(A, N, H), "w2": f(A, N, H), "b1": f(A, H), "b2": f(A, N),
              "c1m": f(N, H), "c1p": f(N, H), "grads": f(A + 1, S), "gW1": f(A, H, N), "gC1": f(H, A, N),
-             "scratch": f(int(lib.sy_ppo_scratch_floats(A, N, H))), "rows": torch.zeros(max(self.minibatch, 1), dtype=torch.int32, device=dev),
-             "actor_loss": f(), "critic_loss": f()}
+             "scratch": f(int(lib.sy_ppo_scratch_floats(A, N, H))), "actor_loss": f(), "critic_loss": f()}
         NH, g = N * H, z["grads"]
         DN = (max(N, H) + 3) & ~3
         oC, oD, oE = 2 * NH, 2 * NH + H, 2 * NH + H + DN
@@ -117,8 +116,9 @@ class MappoUpdater:
         self._fz = z
         return z
 
-    def _step_fused(self, z, src, num_rows):
-        """One minibatch: parameters -> kernel layouts, sy_mappo_ppo_grad, gradients -> torch layouts, Adam."""
+    def _step_fused(self, z, num_rows, row0=0):
+        """One minibatch (image rows row0 .. row0 + num_rows - 1; under a captured graph the device word z['row0'] decides):
+        parameters -> kernel layouts, sy_mappo_ppo_grad, gradients -> torch layouts, Adam."""
         net, A, P, N, H = self.net, self.A, self.P, self.N, self.H
         NH = N * H
         with torch.no_grad():
@@ -131,9 +131,8 @@ class MappoUpdater:
             z["c1m"].copy_(c1[:, 0].t())
             z["c1p"].copy_(c1[:, 1:].sum(1).t())
             ptr = lambda t: C.c_void_p(t.data_ptr())                               # noqa: E731
-            args = z["_lib"].PpoArgs(ptr(src["record"]), int(src["record"].shape[-1]), ptr(src["log_prob"]), ptr(src["adv"]),
-                                     ptr(src["team_ret"]), ptr(z["rows"]), 0, int(num_rows), int(src["B"]), ptr(self.ell),
-                                     ptr(src["env_graph"]), P, N, H, ptr(z["w1t"]), ptr(z["b1"]), ptr(z["w2"]), ptr(z["b2"]),
+            args = z["_lib"].PpoArgs(ptr(z["image"]), int(z["image_rows"]), int(row0), ptr(z["row0"]) if self.use_graph else None,
+                                     int(num_rows), ptr(self.ell), P, N, H, ptr(z["w1t"]), ptr(z["b1"]), ptr(z["w2"]), ptr(z["b2"]),
                                      ptr(z["c1m"]), ptr(z["c1p"]), ptr(net.critic[0].bias), ptr(net.critic[2].weight),
                                      ptr(net.critic[2].bias), self.clip, self.value_coef, ptr(z["scratch"]),
                                      int(z["scratch"].numel()), ptr(z["grads"]))
@@ -151,45 +150,49 @@ class MappoUpdater:
         T, B, A = rec["action"].shape
         R = T * B
         mb = min(self.minibatch, R)
+        nfull = R // mb                                                           # (a ragged tail is dropped, as minibatch PPO does)
         record = rec["record"]
         if record.dtype != torch.int32 or not record.is_contiguous() or record.shape[:2] != (T, B):
             raise ValueError("the fused update reads the packed rollout record: rec['record'] must be the contiguous int32 [T, B, RW] tensor")
         adv = returns if values is None else returns - values.unsqueeze(-1)
         adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).float().contiguous()      # mappo_agent.py:256-258
-        src = {"record": record, "log_prob": rec["log_prob"].float().contiguous(), "adv": adv,
-               "team_ret": returns.sum(-1).float().contiguous(), "B": B,
-               "env_graph": self._env_graph32}
+        log_prob = rec["log_prob"].float().contiguous()
+        team_ret = returns.sum(-1).float().contiguous()
         if self.ell.dtype != torch.int32 or not self.ell.is_contiguous():
             self.ell = self.ell.to(torch.int32).contiguous()
         z = self._fused_state()
-        if z["rows"].numel() < mb:
-            z["rows"] = torch.zeros(mb, dtype=torch.int32, device=self.device)
+        lib, _lib = z["lib"], z["_lib"]
+        rows = nfull * mb
+        need = int(lib.sy_ppo_image_bytes(A, rows))
+        if z.get("image") is None or z["image"].numel() < need or z["image_rows"] != rows:
+            z["image"] = torch.empty(need, dtype=torch.uint8, device=self.device)
+            z["image_rows"] = rows
+            z["row0"] = torch.zeros(1, dtype=torch.int32, device=self.device)
+            z["starts"] = torch.arange(0, rows, mb, dtype=torch.int32, device=self.device)
             self._graph = None
-        perm = torch.randperm(R, device=self.device, generator=generator).to(torch.int32)
-        key = (record.data_ptr(), src["log_prob"].data_ptr(), mb)
-        if self.use_graph and self._graph is not None and self._graph_key[:3] != key:
+        # ONE shuffle of the record per update, as a compact image the gradient launches stream (minibatch i = its rows
+        # i * mb ...): pos / budget / action of the packed record, the log-probabilities, advantages and critic targets
+        perm = torch.randperm(R, device=self.device, generator=generator)[:rows].to(torch.int32)
+        ptr = lambda t: C.c_void_p(t.data_ptr())                                   # noqa: E731
+        pargs = _lib.PpoPackArgs(ptr(record), int(record.shape[-1]), ptr(log_prob), ptr(adv), ptr(team_ret), ptr(perm), 0, rows, B,
+                                 ptr(self._env_graph32), self.P, ptr(z["image"]), int(z["image"].numel()))
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(lib.sy_ppo_pack(C.byref(pargs), stream), "sy_ppo_pack")
+        if self.use_graph and self._graph is not None and self._graph_key != (z["image"].data_ptr(), mb):
             self._graph = None                                                    # other buffers: capture again
-        for i in range(R // mb):                                                  # (a ragged tail is dropped, as minibatch PPO does)
-            z["rows"][:mb].copy_(perm[i * mb:(i + 1) * mb])
+        for i in range(nfull):
             if not self.use_graph:
-                self._step_fused(z, src, mb)
-            elif self._graph is None:
-                # adv / team_ret are fresh tensors on every update: a captured graph reads them from persistent copies
-                z["adv_s"] = torch.empty_like(src["adv"])
-                z["ret_s"] = torch.empty_like(src["team_ret"])
-                z["adv_s"].copy_(src["adv"])
-                z["ret_s"].copy_(src["team_ret"])
-                gsrc = dict(src, adv=z["adv_s"], team_ret=z["ret_s"])
-                self._step_fused(z, gsrc, mb)                                     # first minibatch: eager (warm-up), then capture
+                self._step_fused(z, mb, i * mb)
+                continue
+            z["row0"].copy_(z["starts"][i:i + 1])
+            if self._graph is None:
+                self._step_fused(z, mb)                                           # first minibatch: eager (warm-up), then capture
                 torch.cuda.synchronize(self.device)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.device(self.device), torch.cuda.graph(g):
-                    self._step_fused(z, gsrc, mb)
-                self._graph, self._graph_key = g, key + (gsrc,)
+                    self._step_fused(z, mb)
+                self._graph, self._graph_key = g, (z["image"].data_ptr(), mb)
             else:
-                if i == 0:
-                    z["adv_s"].copy_(src["adv"])
-                    z["ret_s"].copy_(src["team_ret"])
                 self._graph.replay()
         self.last_losses = (z["actor_loss"], z["critic_loss"])
         return self.last_losses

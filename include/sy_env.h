@@ -301,14 +301,19 @@ int sy_returns_advantages(const sy_returns_args *args, void *stream);
  *            env_graph [num_envs] the board of every env
  *
  * sy_mappo_ppo_grad — once per minibatch = image rows row0 .. row0 + num_rows - 1 (row0_dev != NULL: row0 is read from
- * that device word instead, so that one captured graph serves every minibatch), one launch + a reduction launch:
- *   ell uint32 [G][N][16];  w1t [A][N][H], b1 [A][H], w2 [A][N][H] (torch's layout), b2 [A][N]: the actors;  critic: c1m
- *   [N][H] = first layer's MrX block transposed, c1p [N][H] = the SUM of its P police blocks transposed (the critic's input
- *   repeats the police multi-hot P times, mappo_trainer.py:197-208), cb1 [H], c2 [H], cb2 [1]
- *   grads [A + 1][S], S = sy_ppo_slab_floats(N, H): role a < A = actor a: d w1t[a] (N*H) | d w2[a] (N*H) | d b1[a] (H) |
- *   d b2[a] (N, padded to DN = max(N, H) rounded up to 4) | 8 floats: [0] = actor a's share of the actor loss;
- *   role A = critic: d c1m | d c1p (the gradient of EACH police block) | d cb1 | d c2 (H, padded to DN) | [0] = critic
- *   loss (MSE, without value_coef), [1] = d cb2.   scratch: sy_ppo_scratch_floats(A, N, H) floats.
+ * that device word instead, so that one captured graph serves every minibatch), one launch + a reduction launch.
+ * Parameters and gradients share ONE layout, a slab of S = sy_ppo_slab_floats(N, H) floats per network, [A + 1][S]:
+ *   actor a < A:  W1t[a] [N][H] (first layer transposed) | W2[a] [N][H] (torch's layout) | b1[a] [H] | b2[a] [N], padded to
+ *                 DN = max(N, H) rounded up to 4 | 8 floats (grads: [0] = actor a's share of the actor loss)
+ *   critic (A):   C1m [N][H] = first layer's MrX block transposed | C1p [N][H] = the SUM of its P police blocks transposed
+ *                 (the critic's input repeats the police multi-hot P times, mappo_trainer.py:197-208; grads: the gradient
+ *                 of EACH block) | cb1 [H] | c2 [H], padded to DN | 8 floats: [1] = cb2 (grads: [0] = the critic loss, MSE
+ *                 without value_coef, [1] = d cb2)
+ *   ell uint32 [G][N][16];  scratch: sy_ppo_scratch_floats(A, N, H) floats.
+ * Optimiser (optional: adam_m / adam_v [A + 1][S] zero-initialised, adam_step one int32 starting at 0, all device): the
+ * reduction launch also takes torch.optim.Adam's step (no weight decay) on `params` in place — the parameters then stay
+ * resident in the layout the kernels read, and a minibatch is two launches (+ a one-thread tick of the step counter).
+ * The police table C1p moves P steps (each of its P blocks takes one).
  * Limits: hidden a multiple of 4, at most 128; nodes < 65 536.  Sums are accumulated in float64 (LDS), in a different
  * order than a BLAS matmul: parity with the torch form is to float32 rounding. */
 typedef struct sy_ppo_pack_args {
@@ -323,6 +328,8 @@ typedef struct sy_ppo_pack_args {
     int32_t num_police;
     void *image;
     int64_t image_bytes;
+    int64_t shuffle_domain;   /* rows == NULL and > 0: image row i <- record row row0 + pi(i), pi a pseudo-random permutation of */
+    uint64_t shuffle_seed;    /* [0, shuffle_domain) keyed by the seed (a 4-round Feistel network, cycle-walked: no sort)       */
 } sy_ppo_pack_args;
 int64_t sy_ppo_image_bytes(int32_t num_agents, int64_t num_rows);
 int sy_ppo_pack(const sy_ppo_pack_args *args, void *stream);
@@ -335,12 +342,14 @@ typedef struct sy_ppo_args {
     int32_t num_rows;
     const uint32_t *ell;
     int32_t num_police, num_nodes, hidden;
-    const float *w1t, *b1, *w2, *b2;
-    const float *c1m, *c1p, *cb1, *c2, *cb2;
+    float *params;
     float clip, value_coef;
     float *scratch;
     int64_t scratch_floats;
     float *grads;
+    float *adam_m, *adam_v;
+    int32_t *adam_step;
+    float lr, beta1, beta2, eps;
 } sy_ppo_args;
 int32_t sy_ppo_slab_floats(int32_t num_nodes, int32_t hidden);
 int64_t sy_ppo_scratch_floats(int32_t num_agents, int32_t num_nodes, int32_t hidden);

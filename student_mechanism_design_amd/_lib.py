@@ -52,16 +52,16 @@ class PpoPackArgs(C.Structure):
     _fields_ = [("record", C.c_void_p), ("record_words", C.c_int32), ("log_prob", C.c_void_p), ("adv", C.c_void_p),
                 ("team_ret", C.c_void_p), ("rows", C.c_void_p), ("row0", C.c_int32), ("num_rows", C.c_int64),
                 ("num_envs", C.c_int32), ("env_graph", C.c_void_p), ("num_police", C.c_int32), ("image", C.c_void_p),
-                ("image_bytes", C.c_int64)]
+                ("image_bytes", C.c_int64), ("shuffle_domain", C.c_int64), ("shuffle_seed", C.c_uint64)]
 
 
 class PpoArgs(C.Structure):
     _fields_ = [("image", C.c_void_p), ("image_rows", C.c_int64), ("row0", C.c_int32), ("row0_dev", C.c_void_p),
                 ("num_rows", C.c_int32), ("ell", C.c_void_p), ("num_police", C.c_int32), ("num_nodes", C.c_int32),
-                ("hidden", C.c_int32), ("w1t", C.c_void_p), ("b1", C.c_void_p), ("w2", C.c_void_p),
-                ("b2", C.c_void_p), ("c1m", C.c_void_p), ("c1p", C.c_void_p), ("cb1", C.c_void_p), ("c2", C.c_void_p),
-                ("cb2", C.c_void_p), ("clip", C.c_float), ("value_coef", C.c_float), ("scratch", C.c_void_p),
-                ("scratch_floats", C.c_int64), ("grads", C.c_void_p)]
+                ("hidden", C.c_int32), ("params", C.c_void_p), ("clip", C.c_float), ("value_coef", C.c_float),
+                ("scratch", C.c_void_p), ("scratch_floats", C.c_int64), ("grads", C.c_void_p), ("adam_m", C.c_void_p),
+                ("adam_v", C.c_void_p), ("adam_step", C.c_void_p), ("lr", C.c_float), ("beta1", C.c_float),
+                ("beta2", C.c_float), ("eps", C.c_float)]
 
 
 class RolloutBuffers(C.Structure):

@@ -435,14 +435,27 @@ int sy_ppo_pack(const sy_ppo_pack_args* a, void* stream) {
     k.record = a->record; k.RW = a->record_words; k.log_prob = a->log_prob; k.adv = a->adv; k.team_ret = a->team_ret;
     k.rows = a->rows; k.row0 = a->row0; k.count = a->num_rows; k.B = a->num_envs; k.env_graph = a->env_graph; k.A = A;
     k.image = a->image;
+    k.shuffle_domain = 0; k.shuffle_hb = 0; k.shuffle_seed = a->shuffle_seed;
+    if (a->shuffle_domain != 0) {
+        if (a->rows) return fail(SY_ERR_INVALID, "sy_ppo_pack: give `rows` or a shuffle, not both%s");
+        if (a->shuffle_domain < a->num_rows || a->shuffle_domain > 0x40000000LL) return fail(SY_ERR_INVALID, "sy_ppo_pack: shuffle_domain must be in [num_rows, 2^30]%s");
+        int bits = 1;
+        while ((1LL << bits) < a->shuffle_domain) ++bits;
+        k.shuffle_hb = (bits + 1) / 2;
+        k.shuffle_domain = a->shuffle_domain;
+    }
     hipError_t e = sy::launch_ppo_pack(k, (hipStream_t)stream);
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_ppo_pack launch");
 }
 
 int sy_mappo_ppo_grad(const sy_ppo_args* a, void* stream) {
-    if (!a || !a->image || !a->ell || !a->w1t || !a->b1 || !a->w2 || !a->b2 || !a->c1m || !a->c1p || !a->cb1 || !a->c2 || !a->cb2 ||
-        !a->scratch || !a->grads)
+    if (!a || !a->image || !a->ell || !a->params || !a->scratch || !a->grads)
         return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: null argument%s");
+    if (a->adam_m || a->adam_v || a->adam_step) {
+        if (!a->adam_m || !a->adam_v || !a->adam_step) return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: adam_m, adam_v and adam_step go together%s");
+        if (!(a->lr > 0.0f) || !(a->beta1 >= 0.0f && a->beta1 < 1.0f) || !(a->beta2 >= 0.0f && a->beta2 < 1.0f) || !(a->eps > 0.0f))
+            return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: bad Adam constants%s");
+    }
     const int A = a->num_police + 1;
     if (a->num_police < 1 || A > SY_MAX_AGENTS || a->num_nodes < 2 || a->num_nodes > SY_MAX_NODES || a->num_rows < 1 || a->row0 < 0 ||
         a->image_rows < 1)
@@ -451,17 +464,17 @@ int sy_mappo_ppo_grad(const sy_ppo_args* a, void* stream) {
     if (a->hidden < 4 || (a->hidden & 3) || a->hidden > 128) return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: hidden must be a multiple of 4 in [4, 128]%s");
     if (sy::ppo_parts(a->num_nodes, a->hidden) < 1) return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: no LDS for a gradient table row%s");
     if (a->scratch_floats < sy_ppo_scratch_floats(A, a->num_nodes, a->hidden)) return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: scratch too small%s");
-    const uintptr_t al = reinterpret_cast<uintptr_t>(a->w1t) | reinterpret_cast<uintptr_t>(a->w2) | reinterpret_cast<uintptr_t>(a->b1) |
-                         reinterpret_cast<uintptr_t>(a->c1m) | reinterpret_cast<uintptr_t>(a->c1p) | reinterpret_cast<uintptr_t>(a->cb1) |
-                         reinterpret_cast<uintptr_t>(a->c2) | reinterpret_cast<uintptr_t>(a->image);
-    if (al & 15) return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: parameter tables and the image must be 16-byte aligned%s");
+    if ((reinterpret_cast<uintptr_t>(a->params) | reinterpret_cast<uintptr_t>(a->image)) & 15)
+        return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: params and the image must be 16-byte aligned%s");
     sy::PpoArgs k;
     k.image = a->image; k.image_rows = a->image_rows; k.row0 = a->row0; k.row0_dev = a->row0_dev; k.mb = a->num_rows;
     k.ell = a->ell; k.A = A; k.N = a->num_nodes; k.H = a->hidden;
-    k.w1t = a->w1t; k.b1 = a->b1; k.w2 = a->w2; k.b2 = a->b2;
-    k.c1m = a->c1m; k.c1p = a->c1p; k.cb1 = a->cb1; k.c2 = a->c2; k.cb2 = a->cb2;
-    k.clip = a->clip; k.value_coef = a->value_coef; k.partial = a->scratch; k.DN = 0; k.slab = 0; k.parts = 0; k.rpp = 0;
-    hipError_t e = sy::launch_ppo_grad(k, a->grads, (hipStream_t)stream);
+    k.params = a->params;
+    k.clip = a->clip; k.value_coef = a->value_coef; k.partial = a->scratch; k.DN = 0; k.slab = 0; k.parts = 0; k.rpp = 0; k.adam_step = nullptr;
+    sy::PpoAdam ad;
+    ad.params = a->adam_m ? a->params : nullptr; ad.m = a->adam_m; ad.v = a->adam_v; ad.step = a->adam_step;
+    ad.lr = a->lr; ad.beta1 = a->beta1; ad.beta2 = a->beta2; ad.eps = a->eps;
+    hipError_t e = sy::launch_ppo_grad(k, a->grads, ad, (hipStream_t)stream);
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_mappo_ppo_grad launch");
 }
 

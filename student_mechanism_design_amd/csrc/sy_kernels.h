@@ -123,15 +123,17 @@ struct PpoPackArgs {     // rows of a rollout record -> the minibatch image (sy_
     const int32_t* env_graph;
     int32_t A;
     void* image;
+    long long shuffle_domain; int32_t shuffle_hb; uint64_t shuffle_seed;    // rows == nullptr, domain > 0: row0 + permutation(i) of [0, domain)
 };
 struct PpoArgs {
     const void* image; long long image_rows;       // the packed rows of an update (sy_ppo_pack)
     int32_t row0; const int32_t* row0_dev; int32_t mb;   // this minibatch: image rows row0 .. row0 + mb - 1
     const uint32_t* ell;
     int32_t A, N, H;
-    const float *w1t, *b1, *w2, *b2, *c1m, *c1p, *cb1, *c2, *cb2;
+    const float* params;                            // [A + 1][slab]: every network in the slab layout (include/sy_env.h)
     float clip, value_coef;
     float* partial;
+    int32_t* adam_step;
     int32_t DN, slab, parts, rpp;     // filled by the launcher (parts: row ranges a table is cut into; rpp: rows per part)
 };
 size_t ppo_image_size(int A, long long rows);
@@ -139,7 +141,11 @@ hipError_t launch_ppo_pack(const PpoPackArgs& a, hipStream_t stream);
 int ppo_slab_floats(int N, int H);
 int ppo_parts(int N, int H);
 int ppo_blocks_per_role(int A, int N, int H);
-hipError_t launch_ppo_grad(PpoArgs a, float* grads, hipStream_t stream);
+struct PpoAdam {          // params == nullptr: no optimiser step
+    float* params; float* m; float* v; int32_t* step;
+    float lr, beta1, beta2, eps;
+};
+hipError_t launch_ppo_grad(PpoArgs a, float* grads, const PpoAdam& adam, hipStream_t stream);
 
 // the GNN Q-policy (sy_gnn.hip)
 int gnn_padded_features(int F);

@@ -114,12 +114,34 @@ __device__ __forceinline__ PpoRow ppo_fetch_row(const PpoArgs& p, const PpoImage
     return w;
 }
 
-// Pack the rows of an update: image row i <- record row rows[i] (rows == nullptr: row0 + i).
+// A pseudo-random permutation of [0, R) without a sort: a 4-round balanced Feistel network on 2 * hb bits (2^(2 hb) >= R)
+// keyed by the seed, cycle-walked back into range — a bijection, so every row is visited exactly once per update.
+// (torch.randperm on the device is a key sort: ~120 us for 262 144 rows, as much as a minibatch.)
+__device__ __forceinline__ uint32_t ppo_shuffle(uint32_t x, uint32_t R, int hb, uint32_t k0, uint32_t k1) {
+    const uint32_t mask = (1u << hb) - 1u;
+    do {
+        uint32_t l = x >> hb, r = x & mask;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t f = (r + (k & 1 ? k1 : k0) + (uint32_t)k * 0x9E3779B9u) * 0x85EBCA6Bu;
+            f ^= f >> 15; f *= 0xC2B2AE35u; f ^= f >> 13;
+            const uint32_t nl = r;
+            r = l ^ (f & mask);
+            l = nl;
+        }
+        x = (l << hb) | r;
+    } while (x >= R);
+    return x;
+}
+
+// Pack the rows of an update: image row i <- record row rows[i] (rows == nullptr: row0 + i, or the shuffle of i).
 __global__ __launch_bounds__(256) void ppo_pack_kernel(const PpoPackArgs p) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= p.count) return;
     const int A = p.A;
-    const long long r = p.rows ? (long long)p.rows[i] : (long long)p.row0 + i;
+    long long r = p.rows ? (long long)p.rows[i] : (long long)p.row0 + i;
+    if (!p.rows && p.shuffle_domain > 0)
+        r = (long long)p.row0 + ppo_shuffle((uint32_t)i, (uint32_t)p.shuffle_domain, p.shuffle_hb, (uint32_t)p.shuffle_seed, (uint32_t)(p.shuffle_seed >> 32));
     const int32_t* const rec = p.record + (size_t)r * p.RW;
     char* const base = reinterpret_cast<char*>(p.image);
     uint16_t* const posq = reinterpret_cast<uint16_t*>(base) + (size_t)i * 8;
@@ -159,7 +181,7 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
         const int tot = p.rpp * H + H + p.DN + 8;
         for (int k = threadIdx.x; k < tot; k += blockDim.x) acc[k] = 0.0;
         if (WL) {
-            const ppo_f4* const src = reinterpret_cast<const ppo_f4*>(role < A ? p.w2 + (size_t)role * NH : p.c1p);
+            const ppo_f4* const src = reinterpret_cast<const ppo_f4*>(p.params + (size_t)role * p.slab + NH);
             for (int k = threadIdx.x; k < (NH >> 2); k += blockDim.x) reinterpret_cast<ppo_f4*>(wl)[k] = src[k];
         }
     }
@@ -179,13 +201,15 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
     int i = (blockIdx.x * W + wave) * 4 + u;
     const PpoImage im = ppo_image(p.image, A, p.image_rows);
     const int row0 = p.row0_dev ? *p.row0_dev : p.row0;        // (a device word: a captured graph replays on every minibatch)
+    if (p.adam_step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *p.adam_step += 1;   // Adam's step count: read by the reduction launch
     float loss = 0.0f;
     if (role < A) {
         // ---------------------------------------------------------------- actor `role`
         const int a = role;
-        const float* const w1 = p.w1t + (size_t)a * NH;
-        const float* const w2 = WL ? wl : p.w2 + (size_t)a * NH;
-        const float* const b2 = p.b2 + (size_t)a * N;
+        const float* const th = p.params + (size_t)a * p.slab;      // actor a: W1t [N][H] | W2 [N][H] | b1 [H] | b2 [N]
+        const float* const w1 = th;
+        const float* const w2 = WL ? wl : th + NH;
+        const float* const b2 = th + 2 * NH + H;
 #ifdef SY_PPO_DIAG_NOZ
         const int nit = 0;
 #else
@@ -196,7 +220,7 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
         ppo_f4 b1p[KP], gb1[KP];
 #pragma unroll
         for (int m = 0; m < KP; ++m) {
-            b1p[m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(p.b1 + (size_t)a * H + pk[m]) : zero4;
+            b1p[m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(th + 2 * NH + pk[m]) : zero4;
             gb1[m] = zero4;
         }
         PpoRow nx = ppo_fetch_row<true>(p, im, row0, i, a, j);
@@ -270,73 +294,83 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
             const bool mine = j < n;
             if (mine) lgj += b2j;
             const float mx = row16_max(mine ? lgj : -3.0e38f);
-            const float ex = mine ? expf(lgj - mx) : 0.0f;
+            const float ex = mine ? __expf(lgj - mx) : 0.0f;
             const float se = row16_sum(ex);
             const bool hit = mine && nbj == rw.act;
             const float cm = row16_sum(hit ? 1.0f : 0.0f);
             const float la = row16_sum(hit ? lgj : 0.0f);
             // clipped surrogate (mappo_agent.py:284-291) and its derivative with respect to the new log-probability
             const bool valid = rw.act >= 0 && cm > 0.0f;          // an agent without a legal action: ratio 1, no gradient
-            const float lse = valid ? mx + logf(se) : 0.0f;
+            const float lse = valid ? mx + __logf(se) : 0.0f;
             const float icm = valid ? 1.0f / cm : 0.0f;
             const float new_lp = valid ? la * icm - lse : 0.0f;
-            const float ratio = expf(new_lp - (valid ? rw.olp : 0.0f));
+            const float ratio = __expf(new_lp - (valid ? rw.olp : 0.0f));
             const float s1 = ratio * rw.adv, s2 = fminf(fmaxf(ratio, lo), hi) * rw.adv;
             if (rw.on && j == 0) loss -= fminf(s1, s2) * inv;
             const bool within = ratio >= lo && ratio <= hi;
             const float G = (rw.on && valid && (within || s1 < s2)) ? -inv * rw.adv * ratio : 0.0f;   // (a clipped sample has no gradient)
-            const float dlj = (mine && G != 0.0f) ? G * ((hit ? icm : 0.0f) - expf(lgj - lse)) : 0.0f;              // d loss / d logit of entry j
+            const float dlj = (mine && G != 0.0f) ? G * ((hit ? icm : 0.0f) - __expf(lgj - lse)) : 0.0f;              // d loss / d logit of entry j
             if (bal(G != 0.0f) != 0ull) {
                 if (smalls && mine && G != 0.0f) lds_add(gD + nbj, dlj);
-                ppo_f4 dh[KP];
+                if (tab == 1) {
+                    // ---- the W2 table: d W2[n_e] += d l_e h — no second-layer rows, no hidden-layer gradient
+                    for (int c = 0; 4 * c < nmax; ++c) {
 #pragma unroll
-                for (int m = 0; m < KP; ++m) dh[m] = zero4;
-                for (int c = 0; 4 * c < nmax; ++c) {
-                    ppo_f4 wq[4][KP];
-                    int nbe[4];
+                        for (int t = 0; t < 4; ++t) {
+                            const int e = 4 * c + t;
+                            const int src = e < n ? e : 0;
+                            const int nb = __shfl(nbj, src, 16);
+                            float dl = __shfl(dlj, src, 16);
+                            dl = e < n ? dl : 0.0f;
+                            if (dl != 0.0f && nb >= n0 && nb < n1) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int e = 4 * c + t;
-                        nbe[t] = __shfl(nbj, e < n ? e : 0, 16);
-                        nbe[t] = n > 0 ? nbe[t] : 0;
-                    }
-                    if (c < KEEP) {
-#pragma unroll
-                        for (int k = 0; k < KEEP; ++k)
-                            if (c == k) {
-#pragma unroll
-                                for (int t = 0; t < 4; ++t)
-#pragma unroll
-                                    for (int m = 0; m < KP; ++m) wq[t][m] = wk[k][t][m];
+                                for (int m = 0; m < KP; ++m)
+                                    if (pv[m]) lds_add4(gT + (size_t)(nb - n0) * H + pk[m], dl * h[m]);
                             }
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-#pragma unroll
-                            for (int m = 0; m < KP; ++m)
-                                wq[t][m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(w2 + (size_t)nbe[t] * H + pk[m]) : zero4;
-                    }
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const int e = 4 * c + t;
-                        float dl = __shfl(dlj, e < n ? e : 0, 16);
-                        dl = e < n ? dl : 0.0f;
-#pragma unroll
-                        for (int m = 0; m < KP; ++m) dh[m] += dl * wq[t][m];
-                        if (tab == 1 && dl != 0.0f && nbe[t] >= n0 && nbe[t] < n1) {
-#pragma unroll
-                            for (int m = 0; m < KP; ++m)
-                                if (pv[m]) lds_add4(gT + (size_t)(nbe[t] - n0) * H + pk[m], dl * h[m]);
                         }
                     }
-                }
-                ppo_f4 dz[KP];
+                } else {
+                    // ---- the W1t table: dh = sum_e d l_e W2[n_e], dz = dh [z > 0], d W1t[node] += dz for the observation's nodes
+                    ppo_f4 dh[KP];
 #pragma unroll
-                for (int m = 0; m < KP; ++m) {
-                    dz[m] = gate4(z[m], dh[m]);
-                    gb1[m] += dz[m];
-                }
-                if (tab == 0) {
+                    for (int m = 0; m < KP; ++m) dh[m] = zero4;
+                    for (int c = 0; 4 * c < nmax; ++c) {
+                        ppo_f4 wq[4][KP];
+                        if (c < KEEP) {
+#pragma unroll
+                            for (int k = 0; k < KEEP; ++k)
+                                if (c == k) {
+#pragma unroll
+                                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                                        for (int m = 0; m < KP; ++m) wq[t][m] = wk[k][t][m];
+                                }
+                        } else {
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) {
+                                const int e = 4 * c + t;
+                                int nb = __shfl(nbj, e < n ? e : 0, 16);
+                                nb = n > 0 ? nb : 0;
+#pragma unroll
+                                for (int m = 0; m < KP; ++m)
+                                    wq[t][m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(w2 + (size_t)nb * H + pk[m]) : zero4;
+                            }
+                        }
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const int e = 4 * c + t;
+                            float dl = __shfl(dlj, e < n ? e : 0, 16);
+                            dl = e < n ? dl : 0.0f;
+#pragma unroll
+                            for (int m = 0; m < KP; ++m) dh[m] += dl * wq[t][m];
+                        }
+                    }
+                    ppo_f4 dz[KP];
+#pragma unroll
+                    for (int m = 0; m < KP; ++m) {
+                        dz[m] = gate4(z[m], dh[m]);
+                        gb1[m] += dz[m];
+                    }
                     for (int it = 0; it < nit; ++it) {
                         const int node = __shfl(rw.posv, a == 0 ? 0 : 1 + it, 16);
                         if (G != 0.0f && node >= n0 && node < n1) {
@@ -356,15 +390,16 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
     } else {
         // ---------------------------------------------------------------- the central critic (mappo_agent.py:32-44, :260-265)
         const float inv = 1.0f / (float)p.mb;
+        const float* const th = p.params + (size_t)A * p.slab;      // critic: C1m [N][H] | C1p [N][H] | cb1 [H] | c2 [H] (DN) | 8: [1] = cb2
         ppo_f4 cb1p[KP], c2p[KP], gcb1[KP], gc2[KP];
 #pragma unroll
         for (int m = 0; m < KP; ++m) {
-            cb1p[m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(p.cb1 + pk[m]) : zero4;
-            c2p[m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(p.c2 + pk[m]) : zero4;
+            cb1p[m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(th + 2 * NH + pk[m]) : zero4;
+            c2p[m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(th + 2 * NH + H + pk[m]) : zero4;
             gcb1[m] = zero4;
             gc2[m] = zero4;
         }
-        const float cb2 = p.cb2[0];
+        const float cb2 = th[2 * NH + H + p.DN + 1];
         float gcb2 = 0.0f;
         PpoRow nx = ppo_fetch_row<false>(p, im, row0, i, 0, j);
         for (; __builtin_amdgcn_readfirstlane(i - u) < p.mb; i += stride) {
@@ -374,7 +409,7 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
             for (int m = 0; m < KP; ++m) z[m] = cb1p[m];
             for (int it = 0; it < A; ++it) {                         // item 0: MrX's node on c1m; items 1..P: police nodes on c1p
                 const int node = __shfl(rw.posv, it, 16);
-                const float* const tab = it == 0 ? p.c1m : (WL ? wl : p.c1p);
+                const float* const tab = it == 0 ? th : (WL ? wl : th + NH);
 #pragma unroll
                 for (int m = 0; m < KP; ++m)
                     if (pv[m]) z[m] += *reinterpret_cast<const ppo_f4*>(tab + (size_t)node * H + pk[m]);
@@ -434,8 +469,13 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
         for (int k = threadIdx.x; k < p.DN + 8; k += blockDim.x) dst[2 * NH + H + k] = (float)gD[k];
 }
 
-// grads[t] = sum over the blocks of a role of their partial tables
-__global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict__ partial, int nb, int total, float* __restrict__ out) {
+// grads[t] = sum over the blocks of a role of their partial tables; with an optimiser state the Adam step of
+// torch.optim.Adam (no weight decay, no amsgrad) follows in the same thread: exp_avg = b1 m + (1 - b1) g,
+// exp_avg_sq = b2 v + (1 - b2) g^2, param -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).
+// The slab has slots that are not parameters (the loss sums, padding): they are left alone.  The critic's police table is
+// the SUM of its P blocks, every one of which takes the step: the sum moves P steps.
+__global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict__ partial, int nb, int total, float* __restrict__ out,
+                                                         const PpoAdam ad, int A, int N, int H, int DN, int slab) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
@@ -447,7 +487,21 @@ __global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict
         s3 += partial[(size_t)(b + 3) * total + t];
     }
     for (; b < nb; ++b) s0 += partial[(size_t)b * total + t];
-    out[t] = (s0 + s1) + (s2 + s3);
+    const float g = (s0 + s1) + (s2 + s3);
+    out[t] = g;
+    if (ad.params == nullptr) return;
+    const int role = t / slab, off = t - role * slab, NH = N * H, oE = 2 * NH + H + DN;
+    const bool is_param = role < A ? off < 2 * NH + H + N : (off < 2 * NH + 2 * H || off == oE + 1);
+    if (!is_param) return;
+    const int step = *ad.step;                          // (advanced by the gradient launch)
+    const float bc1 = 1.0f - powf(ad.beta1, (float)step), bc2 = 1.0f - powf(ad.beta2, (float)step);
+    const float m = ad.beta1 * ad.m[t] + (1.0f - ad.beta1) * g;
+    const float v = ad.beta2 * ad.v[t] + (1.0f - ad.beta2) * g * g;
+    ad.m[t] = m;
+    ad.v[t] = v;
+    const float denom = sqrtf(v) / sqrtf(bc2) + ad.eps;
+    const float scale = (role == A && off >= NH && off < 2 * NH) ? (float)(A - 1) : 1.0f;
+    ad.params[t] -= scale * (ad.lr / bc1) * (m / denom);
 }
 
 // ---- launchers
@@ -487,7 +541,8 @@ hipError_t launch_ppo_pack(const PpoPackArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
-hipError_t launch_ppo_grad(PpoArgs a, float* grads, hipStream_t stream) {
+hipError_t launch_ppo_grad(PpoArgs a, float* grads, const PpoAdam& adam, hipStream_t stream) {
+    a.adam_step = adam.params ? adam.step : nullptr;
     a.DN = ((a.N > a.H ? a.N : a.H) + 3) & ~3;
     a.slab = ppo_slab_floats(a.N, a.H);
     a.parts = ppo_parts(a.N, a.H);
@@ -509,7 +564,8 @@ hipError_t launch_ppo_grad(PpoArgs a, float* grads, hipStream_t stream) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int total = (a.A + 1) * a.slab;
-    hipLaunchKernelGGL(ppo_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, a.partial, nb, total, grads);
+    hipLaunchKernelGGL(ppo_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, a.partial, nb, total, grads, adam, a.A, a.N, a.H,
+                       a.DN, a.slab);
     return hipGetLastError();
 }
 

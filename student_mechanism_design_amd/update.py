@@ -18,9 +18,11 @@ What makes it fast (round 2's plain-torch form spent 35.7 ms per update of 1.3 M
 `fused=True` (the default on a GPU) goes further: loss AND gradient of
 a minibatch come from ONE HIP kernel, `sy_mappo_ppo_grad` (include/sy_env.h, csrc/sy_ppo.hip), which reads the packed
 rollout record in place through the minibatch's row indices (no shuffled copy of the record), evaluates only the
-affordable logits of every (row, agent) and accumulates each network's gradient in LDS.  torch keeps what it is good at:
-the parameters, Adam, and the few small copies between its layouts and the kernel's.  The torch form above stays as
-`fused=False` — the restatement the kernel is tested against (tests/test_gpu_surface.py).
+affordable logits of every (row, agent) and accumulates each network's gradient in LDS (float64); the launch that sums
+the blocks' tables also takes the Adam step, on parameters that stay RESIDENT in the layout the kernels read (one slab per
+network; the module is refreshed from them at the end of the update and read into them at its start).  A minibatch is two
+launches instead of ~120.  The torch form above stays as `fused=False` — the restatement the kernel is tested against
+(tests/test_gpu_surface.py: every gradient, and the parameters after Adam steps).
 """
 import ctypes as C
 from typing import Dict, Optional
@@ -87,64 +89,96 @@ class MappoUpdater:
 
     # ------------------------------------------------------------------ the HIP gradient kernel
     def _fused_state(self):
-        """Persistent buffers of the fused path (allocated once: a captured graph replays on them): the parameters in the
-        kernel's layouts, the gradient slab and — as views / small transposed copies of it — every parameter's .grad."""
+        """Persistent buffers of the fused path (allocated once: a captured graph replays on them).  Parameters, gradients
+        and Adam's moments share ONE layout — a slab per network, include/sy_env.h — so a minibatch is two launches: the
+        gradient kernel reads `theta`, the reduction applies the Adam step to it in place."""
         if self._fz is not None:
             return self._fz
         from . import _lib
         lib = _lib.load()
-        net, A, P, N, H, dev = self.net, self.A, self.P, self.N, self.H, self.device
+        A, N, H, dev = self.A, self.N, self.H, self.device
         S = int(lib.sy_ppo_slab_floats(N, H))
         assert S == self._slab_floats(N, H)
         f = lambda *shape: torch.zeros(shape, dtype=torch.float32, device=dev)    # noqa: E731
-        z = {"lib": lib, "_lib": _lib, "S": S, "w1": f(A, H, N), "w1t": f(A, N, H), "w2": f(A, N, H), "b1": f(A, H), "b2": f(A, N),
-             "c1m": f(N, H), "c1p": f(N, H), "grads": f(A + 1, S), "gW1": f(A, H, N), "gC1": f(H, A, N),
-             "scratch": f(int(lib.sy_ppo_scratch_floats(A, N, H))), "actor_loss": f(), "critic_loss": f()}
-        NH, g = N * H, z["grads"]
         DN = (max(N, H) + 3) & ~3
-        oC, oD, oE = 2 * NH, 2 * NH + H, 2 * NH + H + DN
-        z["oE"] = oE
+        self._fz = {"lib": lib, "_lib": _lib, "S": S, "theta": f(A + 1, S), "grads": f(A + 1, S), "m": f(A + 1, S), "v": f(A + 1, S),
+                    "step": torch.zeros(1, dtype=torch.int32, device=dev), "scratch": f(int(lib.sy_ppo_scratch_floats(A, N, H))),
+                    "actor_loss": f(), "critic_loss": f(), "oE": 2 * N * H + H + DN, "image": None}
+        return self._fz
+
+    def _slab_views(self, t):
+        """Named views of a [A + 1, S] slab tensor in torch's parameter shapes (transposed where the kernel's layout is)."""
+        A, N, H = self.A, self.N, self.H
+        NH, oE = N * H, self._fz["oE"]
+        act, cri = t[:A], t[A]
+        return {"w1t": act[:, :NH].view(A, N, H), "w2": act[:, NH:2 * NH].view(A, N, H), "b1": act[:, 2 * NH:2 * NH + H],
+                "b2": act[:, 2 * NH + H:2 * NH + H + N], "c1m": cri[:NH].view(N, H), "c1p": cri[NH:2 * NH].view(N, H),
+                "cb1": cri[2 * NH:2 * NH + H], "c2": cri[2 * NH + H:2 * NH + 2 * H], "cb2": cri[oE + 1:oE + 2]}
+
+    @torch.no_grad()
+    def load_from_module(self):
+        """module parameters -> the resident slabs (start of every update: the module stays the source of truth between
+        updates, so checkpoints / manual edits of it are honoured)."""
+        z, net, H, A, N = self._fused_state(), self.net, self.H, self.A, self.N
+        v = self._slab_views(z["theta"])
+        v["w1t"].copy_(torch.stack([a[0].weight for a in net.actors]).transpose(1, 2))
+        v["w2"].copy_(torch.stack([a[2].weight for a in net.actors]))
+        v["b1"].copy_(torch.stack([a[0].bias for a in net.actors]))
+        v["b2"].copy_(torch.stack([a[2].bias for a in net.actors]))
+        c1 = net.critic[0].weight.view(H, A, N)
+        v["c1m"].copy_(c1[:, 0].t())
+        z["c1p_before"] = c1[:, 1:].sum(1).t().contiguous()
+        v["c1p"].copy_(z["c1p_before"])
+        v["cb1"].copy_(net.critic[0].bias)
+        v["c2"].copy_(net.critic[2].weight.view(-1))
+        v["cb2"].copy_(net.critic[2].bias)
+
+    @torch.no_grad()
+    def store_to_module(self):
+        """the resident slabs -> module parameters (end of every update).  The critic's P police blocks all took the same
+        steps (the police table is their sum, moved P steps): each block moves by the table's change / P."""
+        z, net, H, A, N, P = self._fz, self.net, self.H, self.A, self.N, self.P
+        v = self._slab_views(z["theta"])
+        w1 = v["w1t"].transpose(1, 2)
         for a, actor in enumerate(net.actors):
-            actor[0].weight.grad = z["gW1"][a]
-            actor[0].bias.grad = g[a, oC:oC + H]
-            actor[2].weight.grad = g[a, NH:2 * NH].view(N, H)
-            actor[2].bias.grad = g[a, oD:oD + N]
-        net.critic[0].weight.grad = z["gC1"].view(H, A * N)
-        net.critic[0].bias.grad = g[A, oC:oC + H]
-        net.critic[2].weight.grad = g[A, oD:oD + H].view(1, H)
-        net.critic[2].bias.grad = g[A, oE + 1:oE + 2]
-        self._fz = z
-        return z
+            actor[0].weight.copy_(w1[a])
+            actor[0].bias.copy_(v["b1"][a])
+            actor[2].weight.copy_(v["w2"][a])
+            actor[2].bias.copy_(v["b2"][a])
+        c1 = net.critic[0].weight.view(H, A, N)
+        c1[:, 0].copy_(v["c1m"].t())
+        c1[:, 1:].add_(((v["c1p"] - z["c1p_before"]) / P).t().unsqueeze(1))
+        net.critic[0].bias.copy_(v["cb1"])
+        net.critic[2].weight.view(-1).copy_(v["c2"])
+        net.critic[2].bias.copy_(v["cb2"])
+
+    def fused_gradients(self):
+        """The last minibatch's gradient in torch's parameter shapes, keyed like `net.named_parameters()` (tests)."""
+        g = self._slab_views(self._fz["grads"])
+        out = {}
+        for a in range(self.A):
+            out["actors.%d.0.weight" % a] = g["w1t"][a].t()
+            out["actors.%d.0.bias" % a] = g["b1"][a]
+            out["actors.%d.2.weight" % a] = g["w2"][a]
+            out["actors.%d.2.bias" % a] = g["b2"][a]
+        c1g = torch.stack([g["c1m"].t()] + [g["c1p"].t()] * self.P, dim=1)          # [H, A, N]
+        out["critic.0.weight"] = c1g.reshape(self.H, self.A * self.N)
+        out["critic.0.bias"] = g["cb1"]
+        out["critic.2.weight"] = g["c2"].view(1, self.H)
+        out["critic.2.bias"] = g["cb2"]
+        return out
 
     def _step_fused(self, z, num_rows, row0=0):
         """One minibatch (image rows row0 .. row0 + num_rows - 1; under a captured graph the device word z['row0'] decides):
-        parameters -> kernel layouts, sy_mappo_ppo_grad, gradients -> torch layouts, Adam."""
-        net, A, P, N, H = self.net, self.A, self.P, self.N, self.H
-        NH = N * H
-        with torch.no_grad():
-            torch.stack([a[0].weight for a in net.actors], out=z["w1"])
-            z["w1t"].copy_(z["w1"].transpose(1, 2))
-            torch.stack([a[2].weight for a in net.actors], out=z["w2"])
-            torch.stack([a[0].bias for a in net.actors], out=z["b1"])
-            torch.stack([a[2].bias for a in net.actors], out=z["b2"])
-            c1 = net.critic[0].weight.view(H, A, N)
-            z["c1m"].copy_(c1[:, 0].t())
-            z["c1p"].copy_(c1[:, 1:].sum(1).t())
-            ptr = lambda t: C.c_void_p(t.data_ptr())                               # noqa: E731
-            args = z["_lib"].PpoArgs(ptr(z["image"]), int(z["image_rows"]), int(row0), ptr(z["row0"]) if self.use_graph else None,
-                                     int(num_rows), ptr(self.ell), P, N, H, ptr(z["w1t"]), ptr(z["b1"]), ptr(z["w2"]), ptr(z["b2"]),
-                                     ptr(z["c1m"]), ptr(z["c1p"]), ptr(net.critic[0].bias), ptr(net.critic[2].weight),
-                                     ptr(net.critic[2].bias), self.clip, self.value_coef, ptr(z["scratch"]),
-                                     int(z["scratch"].numel()), ptr(z["grads"]))
-            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-            z["_lib"].check(z["lib"].sy_mappo_ppo_grad(C.byref(args), stream), "sy_mappo_ppo_grad")
-            g = z["grads"]
-            z["gW1"].copy_(g[:A, :NH].view(A, N, H).transpose(1, 2))
-            z["gC1"][:, 0].copy_(g[A, :NH].view(N, H).t())
-            z["gC1"][:, 1:].copy_(g[A, NH:2 * NH].view(N, H).t().unsqueeze(1).expand(H, P, N))
-            z["actor_loss"].copy_(g[:A, z["oE"]].sum())
-            z["critic_loss"].copy_(g[A, z["oE"]])
-        self.opt.step()
+        sy_mappo_ppo_grad = the gradient launch + the reduction that takes the Adam step on the resident parameters."""
+        ptr = lambda t: C.c_void_p(t.data_ptr())                                   # noqa: E731
+        b1, b2 = self.opt.param_groups[0]["betas"]
+        args = z["_lib"].PpoArgs(ptr(z["image"]), int(z["image_rows"]), int(row0), ptr(z["row0"]) if self.use_graph else None,
+                                 int(num_rows), ptr(self.ell), self.P, self.N, self.H, ptr(z["theta"]), self.clip, self.value_coef,
+                                 ptr(z["scratch"]), int(z["scratch"].numel()), ptr(z["grads"]), ptr(z["m"]), ptr(z["v"]), ptr(z["step"]),
+                                 float(self.opt.param_groups[0]["lr"]), float(b1), float(b2), float(self.opt.param_groups[0]["eps"]))
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        z["_lib"].check(z["lib"].sy_mappo_ppo_grad(C.byref(args), stream), "sy_mappo_ppo_grad")
 
     def _update_fused(self, rec, returns, values, generator):
         T, B, A = rec["action"].shape
@@ -164,18 +198,25 @@ class MappoUpdater:
         lib, _lib = z["lib"], z["_lib"]
         rows = nfull * mb
         need = int(lib.sy_ppo_image_bytes(A, rows))
-        if z.get("image") is None or z["image"].numel() < need or z["image_rows"] != rows:
+        if z["image"] is None or z["image"].numel() < need or z["image_rows"] != rows:
             z["image"] = torch.empty(need, dtype=torch.uint8, device=self.device)
             z["image_rows"] = rows
             z["row0"] = torch.zeros(1, dtype=torch.int32, device=self.device)
             z["starts"] = torch.arange(0, rows, mb, dtype=torch.int32, device=self.device)
             self._graph = None
+        self.load_from_module()
         # ONE shuffle of the record per update, as a compact image the gradient launches stream (minibatch i = its rows
         # i * mb ...): pos / budget / action of the packed record, the log-probabilities, advantages and critic targets
-        perm = torch.randperm(R, device=self.device, generator=generator)[:rows].to(torch.int32)
+        # (the shuffle is a keyed permutation computed inside the pack kernel — no sort; keyed by the generator's seed, or
+        # torch's, and the number of updates so far)
+        self._updates = getattr(self, "_updates", 0) + 1
+        base = generator.initial_seed() if generator is not None else torch.initial_seed()
+        seed = (int(base) * 0x9E3779B97F4A7C15 + self._updates * 0xD1B54A32D192ED03 + 0x85EBCA6B) & (2 ** 64 - 1)
+        if generator is not None:
+            seed = (int(base) * 0x9E3779B97F4A7C15 + 0x85EBCA6B) & (2 ** 64 - 1)   # an explicit generator decides alone (reproducible)
         ptr = lambda t: C.c_void_p(t.data_ptr())                                   # noqa: E731
-        pargs = _lib.PpoPackArgs(ptr(record), int(record.shape[-1]), ptr(log_prob), ptr(adv), ptr(team_ret), ptr(perm), 0, rows, B,
-                                 ptr(self._env_graph32), self.P, ptr(z["image"]), int(z["image"].numel()))
+        pargs = _lib.PpoPackArgs(ptr(record), int(record.shape[-1]), ptr(log_prob), ptr(adv), ptr(team_ret), None, 0, rows, B,
+                                 ptr(self._env_graph32), self.P, ptr(z["image"]), int(z["image"].numel()), R, seed)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(lib.sy_ppo_pack(C.byref(pargs), stream), "sy_ppo_pack")
         if self.use_graph and self._graph is not None and self._graph_key != (z["image"].data_ptr(), mb):
@@ -194,6 +235,10 @@ class MappoUpdater:
                 self._graph, self._graph_key = g, (z["image"].data_ptr(), mb)
             else:
                 self._graph.replay()
+        oE = z["oE"]
+        z["actor_loss"].copy_(z["grads"][:A, oE].sum())
+        z["critic_loss"].copy_(z["grads"][A, oE])
+        self.store_to_module()
         self.last_losses = (z["actor_loss"], z["critic_loss"])
         return self.last_losses
 

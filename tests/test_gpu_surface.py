@@ -1061,12 +1061,20 @@ def test_fused_ppo_gradient_matches_the_torch_form(sy, N, P, H, B, T):
     lf = [float(x) for x in up_f.update(rec, ret)]
     np.testing.assert_allclose(lf, lt, rtol=2e-5, atol=1e-7)
     assert lt[1] > 0            # (the first step's actor loss is -mean(standardised advantage) = 0 up to rounding: ratio 1)
+    fg = up_f.fused_gradients()
     for (name, pt), (_, pf) in zip(net_t.named_parameters(), net_f.named_parameters()):
-        gt, gf = _np(pt.grad), _np(pf.grad)
+        gt, gf = _np(pt.grad), _np(fg[name])
         scale = float(np.abs(gt).max())
         assert scale > 0, name
         np.testing.assert_allclose(gf, gt, rtol=1e-4, atol=2e-6 * scale, err_msg=name)
         np.testing.assert_allclose(_np(pf), _np(pt), rtol=0, atol=2e-5, err_msg=name)       # after the Adam step
+    # two more full-batch updates: Adam's moments and bias corrections (in the reduction launch) track torch.optim.Adam
+    for _ in range(2):
+        lt = [float(x) for x in up_t.update(rec, ret)]
+        lf = [float(x) for x in up_f.update(rec, ret)]
+        np.testing.assert_allclose(lf, lt, rtol=2e-4, atol=1e-6)
+    for (name, pt), (_, pf) in zip(net_t.named_parameters(), net_f.named_parameters()):
+        np.testing.assert_allclose(_np(pf), _np(pt), rtol=0, atol=1e-4, err_msg=name)
     # minibatches (a different shuffle per path: compare what does not depend on it — finite losses, parameters that moved)
     g = torch.Generator(device=env.device)
     up_f2 = MappoUpdater(net_f, env.ell, env.env_graph, minibatch=max(R // 4, 1), fused=True, lr=1e-3)
@@ -1078,8 +1086,8 @@ def test_fused_ppo_gradient_matches_the_torch_form(sy, N, P, H, B, T):
 
 
 def test_fused_ppo_update_replays_as_a_graph(sy):
-    """use_graph=True on the fused path: the minibatch step (pack, sy_mappo_ppo_grad, unpack, Adam) captured once and
-    replayed gives the same parameters as the eager path, update after update (same shuffles)."""
+    """use_graph=True on the fused path: the minibatch step (the gradient launch + the reduction / Adam launch) captured
+    once and replayed gives the same parameters as the eager path, update after update (same shuffles)."""
     import copy
     from student_mechanism_design_amd import collector as col, policies as pol
     from student_mechanism_design_amd.update import MappoUpdater
@@ -1103,3 +1111,49 @@ def test_fused_ppo_update_replays_as_a_graph(sy):
     for pe, pg in zip(net_e.parameters(), net_g.parameters()):
         np.testing.assert_allclose(_np(pg), _np(pe), rtol=0, atol=1e-5)
     env.close()
+
+
+@pytest.mark.parametrize("R,rows", [(1000, 1000), (4096, 4096), (777, 512)])
+def test_ppo_pack_shuffle_is_a_permutation(sy, R, rows):
+    """sy_ppo_pack's keyed shuffle (Feistel network + cycle walking, no sort): image rows are distinct record rows — all of
+    them when rows == R —, carry exactly that row's words, differ from the identity and depend on the seed."""
+    import ctypes as C
+    from student_mechanism_design_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    A, B = 4, 8
+    RW = int(lib.sy_record_words(A))
+    g = torch.Generator().manual_seed(R)
+    record = torch.randint(0, 200, (R, RW), dtype=torch.int32, generator=g).to(dev)
+    log_prob = torch.rand(R, A, generator=g).to(dev)
+    adv = torch.randn(R, A, generator=g).to(dev)
+    team = torch.arange(R, dtype=torch.float32, device=dev)              # the critic target names the record row
+    env_graph = torch.arange(B, dtype=torch.int32, device=dev)
+    ptr = lambda t: C.c_void_p(t.data_ptr())                             # noqa: E731
+
+    def pack(seed):
+        image = torch.zeros(int(lib.sy_ppo_image_bytes(A, rows)), dtype=torch.uint8, device=dev)
+        args = _lib.PpoPackArgs(ptr(record), RW, ptr(log_prob), ptr(adv), ptr(team), None, 0, rows, B, ptr(env_graph), A - 1,
+                                ptr(image), image.numel(), R, seed)
+        _lib.check(lib.sy_ppo_pack(C.byref(args), None), "sy_ppo_pack")
+        torch.cuda.synchronize()
+        posq = image[:rows * 16].view(torch.int16).view(rows, 8)
+        agent = image[rows * 16:rows * 16 * (1 + A)].view(torch.int32).view(A, rows, 4)
+        tail = image[rows * 16 * (1 + A):].view(torch.int32).view(rows, 2)
+        return posq, agent, tail
+
+    posq, agent, tail = pack(12345)
+    src = tail[:, 0].view(torch.float32).long()                          # record row of every image row
+    assert int(src.min()) >= 0 and int(src.max()) < R and torch.unique(src).numel() == rows
+    if rows == R:
+        assert bool((torch.sort(src).values == torch.arange(R, device=dev)).all())
+    assert int((src == torch.arange(rows, device=dev)).sum()) < rows // 4
+    np.testing.assert_array_equal(_np(posq[:, :A].int()), _np(record[src][:, 2 * A:3 * A]))
+    np.testing.assert_array_equal(_np(tail[:, 1]), _np(env_graph[src % B]))
+    for a in range(A):
+        np.testing.assert_array_equal(_np(agent[a, :, 0]), _np(record[src][:, 3 * A + a]))
+        np.testing.assert_array_equal(_np(agent[a, :, 1]), _np(record[src][:, 4 * A + a]))
+        np.testing.assert_array_equal(_np(agent[a, :, 2].view(torch.float32)), _np(log_prob[src][:, a]))
+        np.testing.assert_array_equal(_np(agent[a, :, 3].view(torch.float32)), _np(adv[src][:, a]))
+    src2 = pack(54321)[2][:, 0].view(torch.float32).long()
+    assert int((src2 == src).sum()) < rows // 4

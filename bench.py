@@ -143,7 +143,7 @@ def config3_record(args, boards, weights, device):
     fused = pol.DeviceMappoPolicy(net, seed=3)
     env.set_policy(fused)
     out = env.alloc_rollout(T)
-    up = MappoUpdater(net, env.ell, env.env_graph, minibatch=32768, use_graph=not args.config3_eager)
+    up = MappoUpdater(net, env.ell, env.env_graph, minibatch=32768, use_graph=args.config3_graph)
 
     def timed(fn):
         torch.cuda.synchronize(device)
@@ -175,7 +175,7 @@ def config3_record(args, boards, weights, device):
     n = T * B * A
     rec3 = {"what": "BASELINE configs[2]: learned policy (MAPPO actors, hidden 64) sampling inside the fused rollout, T=64 x "
                     "%d envs, returns in one HIP launch, one minibatch-PPO pass (minibatch 32768 env-steps: %s%s), weights "
-                    "refreshed; medians of %d iterations" % (B, "loss + gradient in one HIP kernel, sy_mappo_ppo_grad, then fused Adam"
+                    "refreshed; medians of %d iterations" % (B, "loss + gradient in one HIP kernel on resident parameters, Adam in its reduction launch: sy_mappo_ppo_grad"
                                                              if up.fused else "torch autograd", ", each step one HIP graph" if up.use_graph else "", iters),
             "kernel": env.rollout_kernel_name(), "update_path": "sy_mappo_ppo_grad" if up.fused else "torch", "agent_transitions_per_iteration": n,
             "collect_ms": med("collect"), "returns_ms": med("returns"), "update_ms": med("update"),
@@ -297,7 +297,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the separately timed trajectory all-gather")
     ap.add_argument("--step-api", action="store_true", help="also time the per-step sy_env_step launch path")
     ap.add_argument("--no-config3", action="store_true", help="skip the configs[2] sub-record (learned policy + update)")
-    ap.add_argument("--config3-eager", action="store_true", help="configs[2] sub-record: eager minibatch steps (no HIP graph)")
+    ap.add_argument("--config3-graph", action="store_true", help="configs[2] sub-record: replay every minibatch step as one HIP graph "
+                    "(no gain on the fused update: a minibatch is two launches)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

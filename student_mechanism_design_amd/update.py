@@ -104,7 +104,34 @@ class MappoUpdater:
         self._fz = {"lib": lib, "_lib": _lib, "S": S, "theta": f(A + 1, S), "grads": f(A + 1, S), "m": f(A + 1, S), "v": f(A + 1, S),
                     "step": torch.zeros(1, dtype=torch.int32, device=dev), "scratch": f(int(lib.sy_ppo_scratch_floats(A, N, H))),
                     "actor_loss": f(), "critic_loss": f(), "oE": 2 * N * H + H + DN, "image": None}
+        # The actors' parameters become views of four stacked tensors (same values, same Parameter objects): the module <->
+        # slab copies are then one strided copy per kind instead of one per actor and kind.
+        with torch.no_grad():
+            acts = self.net.actors
+            mir = {"w1": torch.stack([a[0].weight for a in acts]), "b1": torch.stack([a[0].bias for a in acts]),
+                   "w2": torch.stack([a[2].weight for a in acts]), "b2": torch.stack([a[2].bias for a in acts])}
+            for a, actor in enumerate(acts):
+                actor[0].weight.data, actor[0].bias.data = mir["w1"][a], mir["b1"][a]
+                actor[2].weight.data, actor[2].bias.data = mir["w2"][a], mir["b2"][a]
+        self._fz["mirror"] = mir
         return self._fz
+
+    def _mirrors(self):
+        """The stacked actor parameters, re-stacked if somebody re-pointed a parameter's storage since (load_state_dict
+        copies in place and keeps the views; `.data = ...` assignments do not)."""
+        mir, acts = self._fz["mirror"], self.net.actors
+        same = all(acts[a][0].weight.data_ptr() == mir["w1"][a].data_ptr() and acts[a][2].weight.data_ptr() == mir["w2"][a].data_ptr() and
+                   acts[a][0].bias.data_ptr() == mir["b1"][a].data_ptr() and acts[a][2].bias.data_ptr() == mir["b2"][a].data_ptr()
+                   for a in range(self.A))
+        if not same:
+            with torch.no_grad():
+                mir = {"w1": torch.stack([a[0].weight for a in acts]), "b1": torch.stack([a[0].bias for a in acts]),
+                       "w2": torch.stack([a[2].weight for a in acts]), "b2": torch.stack([a[2].bias for a in acts])}
+                for a, actor in enumerate(acts):
+                    actor[0].weight.data, actor[0].bias.data = mir["w1"][a], mir["b1"][a]
+                    actor[2].weight.data, actor[2].bias.data = mir["w2"][a], mir["b2"][a]
+            self._fz["mirror"] = mir
+        return mir
 
     def _slab_views(self, t):
         """Named views of a [A + 1, S] slab tensor in torch's parameter shapes (transposed where the kernel's layout is)."""
@@ -121,10 +148,11 @@ class MappoUpdater:
         updates, so checkpoints / manual edits of it are honoured)."""
         z, net, H, A, N = self._fused_state(), self.net, self.H, self.A, self.N
         v = self._slab_views(z["theta"])
-        v["w1t"].copy_(torch.stack([a[0].weight for a in net.actors]).transpose(1, 2))
-        v["w2"].copy_(torch.stack([a[2].weight for a in net.actors]))
-        v["b1"].copy_(torch.stack([a[0].bias for a in net.actors]))
-        v["b2"].copy_(torch.stack([a[2].bias for a in net.actors]))
+        mir = self._mirrors()
+        v["w1t"].copy_(mir["w1"].transpose(1, 2))
+        v["w2"].copy_(mir["w2"])
+        v["b1"].copy_(mir["b1"])
+        v["b2"].copy_(mir["b2"])
         c1 = net.critic[0].weight.view(H, A, N)
         v["c1m"].copy_(c1[:, 0].t())
         z["c1p_before"] = c1[:, 1:].sum(1).t().contiguous()
@@ -139,12 +167,11 @@ class MappoUpdater:
         steps (the police table is their sum, moved P steps): each block moves by the table's change / P."""
         z, net, H, A, N, P = self._fz, self.net, self.H, self.A, self.N, self.P
         v = self._slab_views(z["theta"])
-        w1 = v["w1t"].transpose(1, 2)
-        for a, actor in enumerate(net.actors):
-            actor[0].weight.copy_(w1[a])
-            actor[0].bias.copy_(v["b1"][a])
-            actor[2].weight.copy_(v["w2"][a])
-            actor[2].bias.copy_(v["b2"][a])
+        mir = z["mirror"]                                   # (the parameters are views of these: load_from_module checked)
+        mir["w1"].copy_(v["w1t"].transpose(1, 2))
+        mir["w2"].copy_(v["w2"])
+        mir["b1"].copy_(v["b1"])
+        mir["b2"].copy_(v["b2"])
         c1 = net.critic[0].weight.view(H, A, N)
         c1[:, 0].copy_(v["c1m"].t())
         c1[:, 1:].add_(((v["c1p"] - z["c1p_before"]) / P).t().unsqueeze(1))

@@ -162,6 +162,9 @@ template <int KP, int KEEP, bool WL>   // KP: 16-byte pieces of a hidden vector 
                                        // WL: the network's second-layer table (critic: its police block) is staged in LDS
 __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
     extern __shared__ double acc[];
+#ifdef SY_PPO_DIAG_ONLY          // timing-only diagnostic: one role's blocks work, the others leave at once
+    if ((int)blockIdx.y != SY_PPO_DIAG_ONLY) return;
+#endif
     const int N = p.N, H = p.H, NH = N * H, A = p.A, P = A - 1;
     // blockIdx.y = ((network * 2) + table) * parts + part: this block accumulates rows [n0, n1) of ONE table of one network
     const int role = blockIdx.y / (2 * p.parts);                      // network: actor a < A, or the critic (A)

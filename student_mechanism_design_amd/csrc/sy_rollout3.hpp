@@ -314,15 +314,19 @@ struct HalfScan {
         }
         wave_lds_fence();
         float Lm = ordered_f32(*lds_at<int>(pl.sl + 8u));
-        // ---- phase 2: the sum of exp(logit - max)
+        // ---- phase 2: the sum of exp(logit - max), in 2^-26 fixed point: every term is in (0, 1] and there are at most 16,
+        // so the sum fits 31 bits; an integer LDS add runs ~20x faster than ds_add_f32 on gfx950
+        // (tools/probes/lds_atomic_probe.hip) and makes the sum — and with it the recorded log-probability — independent of
+        // the order the lanes arrive in
+        constexpr float kSumScale = 67108864.0f, kSumInv = 1.0f / 67108864.0f;
 #pragma unroll
         for (int k = 0; k < NC; ++k)
-            if (lanes(bo[k])) atomicAdd(lds_at_generic<float>(pl.sl + 12u), __expf(l[k] - Lm));
+            if (lanes(bo[k])) atomicAdd(lds_at_generic<unsigned int>(pl.sl + 12u), (unsigned int)(__expf(l[k] - Lm) * kSumScale + 0.5f));
         if (lanes(lead_m)) lds_at<int>(selw)[1] = __popc(qf);
         wave_lds_fence();
         // ---- the reference's underflow rule (mappo_agent.py:123-134), exact only where the cheap bound cannot rule it out
         {
-            const float S = *lds_at<float>(pl.sl + 12u);
+            const float S = (float)*lds_at<unsigned int>(pl.sl + 12u) * kSumInv;
             const bool lead = lanes(lead_m);
             const uint64_t sus = bal(lead && gf != 0u && !(Lm + __logf(S) > pl.thr));
 #ifndef SY_POL_NO_FALLBACK
@@ -341,7 +345,7 @@ struct HalfScan {
                     const bool f = ((fb >> (lane - col)) & 1ull) != 0ull;            // my group's leader bit -> my fallback flag
                     if (f && lanes(lead_m)) {
                         typedef int v4i __attribute__((ext_vector_type(4)));
-                        *lds_at<v4i>(pl.sl) = (v4i){0, 0, f32_ordered(0.0f), __float_as_int((float)__popc(gf))};
+                        *lds_at<v4i>(pl.sl) = (v4i){0, 0, f32_ordered(0.0f), (int)((unsigned int)__popc(gf) << 26)};
                     }
                     wave_lds_fence();
 #pragma unroll
@@ -363,7 +367,7 @@ struct HalfScan {
             const float lw = keyw - gumbel(x_own, (pay >> 10) & 31u);                     // the winner's logit back from its key
             act_v = any ? (int)(pay & 0x3ffu) : -1;
             cost_v = any ? (int)(pay >> 16) : 0;
-            logp_v = any ? (lw - ordered_f32(sv.z)) - __logf(__int_as_float(sv.w)) : 0.0f;
+            logp_v = any ? (lw - ordered_f32(sv.z)) - __logf((float)(unsigned int)sv.w * kSumInv) : 0.0f;
             quirk_cnt = lds_at<int>(selr)[1];
         }
         wave_lds_fence();

@@ -139,17 +139,21 @@ class DeviceMappoPolicy:
         import ctypes as C
         f32 = dict(dtype=torch.float32, device=self.device)
         acts = self.net.actors
+        W1 = torch.stack([a[0].weight for a in acts])                   # [A, H, N]
+        b1 = torch.stack([a[0].bias for a in acts])                     # [A, H]
+        W2 = torch.stack([a[2].weight for a in acts])                   # [A, N, H] (torch layout: a node's row contiguous)
+        b2 = torch.stack([a[2].bias for a in acts])                     # [A, N]
         packed = {
-            "w1t": torch.stack([a[0].weight.t() for a in acts]),        # [A, N, H]
-            "b1": torch.stack([a[0].bias for a in acts]),               # [A, H]
-            "w2t": torch.stack([a[2].weight.t() for a in acts]),        # [A, H, N]
-            "b2": torch.stack([a[2].bias for a in acts]),               # [A, N]
+            "w1t": W1.transpose(1, 2),                                  # [A, N, H]
+            "b1": b1,
+            "w2t": W2.transpose(1, 2),                                  # [A, H, N]
+            "b2": b2,
             "c1t": self.net.critic[0].weight.t(),                       # [N * A, H]
             "cb1": self.net.critic[0].bias,
             "c2": self.net.critic[2].weight.reshape(-1),                # [H]
             "cb2": self.net.critic[2].bias,
-            "w2": torch.stack([a[2].weight for a in acts]),             # [A, N, H] (torch layout: a node's row contiguous)
-            "logit_bound": self._logit_bound(),                         # [A] (the in-kernel underflow rule's cheap test)
+            "w2": W2,
+            "logit_bound": self._logit_bound(W1, b1, W2, b2),           # [A] (the in-kernel underflow rule's cheap test)
         }
         if getattr(self, "_packed", None) is None:
             self._packed = {k: v.to(**f32).contiguous().clone() for k, v in packed.items()}
@@ -160,16 +164,15 @@ class DeviceMappoPolicy:
                 self._packed[k].copy_(v)
 
     @torch.no_grad()
-    def _logit_bound(self) -> torch.Tensor:
+    def _logit_bound(self, W1, b1, W2, b2) -> torch.Tensor:
         """[A] an upper bound of every logit actor a can produce, whatever the observation: the hidden units are
         relu(b1 + sum of `hot` columns of W1) (hot = 1: MrX's one-hot input; P: the police actors' multi-hot input), so
-        h_k <= hmax_k = max(b1_k, 0) + hot * max_n max(W1[k, n], 0) and logit_n <= b2_n + sum_k max(W2[n, k], 0) * hmax_k."""
-        out = []
-        for a, actor in enumerate(self.net.actors):
-            hot = 1 if a == 0 else self.net.P
-            hmax = actor[0].bias.clamp_min(0) + hot * actor[0].weight.clamp_min(0).max(dim=1).values     # [H]
-            out.append((actor[2].bias + actor[2].weight.clamp_min(0) @ hmax).max())
-        return torch.stack(out).float()
+        h_k <= hmax_k = max(b1_k, 0) + hot * max_n max(W1[k, n], 0) and logit_n <= b2_n + sum_k max(W2[n, k], 0) * hmax_k.
+        All actors at once on the stacked parameters (W1 [A, H, N], b1 [A, H], W2 [A, N, H], b2 [A, N])."""
+        hot = torch.full((W1.shape[0], 1), float(self.net.P), device=W1.device)
+        hot[0] = 1.0
+        hmax = b1.clamp_min(0) + hot * W1.clamp_min(0).amax(dim=2)                               # [A, H]
+        return (b2 + torch.bmm(W2.clamp_min(0), hmax.unsqueeze(-1)).squeeze(-1)).amax(dim=1).float()
 
     @torch.no_grad()
     def act(self, obs: Dict[str, torch.Tensor], want_probs: bool = False):

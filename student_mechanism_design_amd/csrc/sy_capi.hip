@@ -415,7 +415,7 @@ int sy_returns_advantages(const sy_returns_args* a, void* stream) {
 int32_t sy_ppo_slab_floats(int32_t num_nodes, int32_t hidden) { return sy::ppo_slab_floats(num_nodes, hidden); }
 
 int64_t sy_ppo_scratch_floats(int32_t num_agents, int32_t num_nodes, int32_t hidden) {
-    return (int64_t)sy::ppo_blocks_per_role(num_agents, num_nodes, hidden) * (num_agents + 1) * sy::ppo_slab_floats(num_nodes, hidden);
+    return (int64_t)sy::ppo_max_blocks_per_role() * (num_agents + 1) * sy::ppo_slab_floats(num_nodes, hidden);
 }
 
 int64_t sy_ppo_image_bytes(int32_t num_agents, int64_t num_rows) {
@@ -462,7 +462,8 @@ int sy_mappo_ppo_grad(const sy_ppo_args* a, void* stream) {
         return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: bad sizes%s");
     if (!a->row0_dev && (int64_t)a->row0 + a->num_rows > a->image_rows) return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: the minibatch ends past the image%s");
     if (a->hidden < 4 || (a->hidden & 3) || a->hidden > 128) return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: hidden must be a multiple of 4 in [4, 128]%s");
-    if (sy::ppo_parts(a->num_nodes, a->hidden) < 1) return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: no LDS for a gradient table row%s");
+    if (sy::ppo_parts(a->num_nodes, a->hidden) < 1 || 2 * (A + 1) * sy::ppo_parts(a->num_nodes, a->hidden) > SY_PPO_MAX_ROLES)
+        return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: nodes x hidden too large (a gradient table is cut into too many row ranges)%s");
     if (a->scratch_floats < sy_ppo_scratch_floats(A, a->num_nodes, a->hidden)) return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: scratch too small%s");
     if ((reinterpret_cast<uintptr_t>(a->params) | reinterpret_cast<uintptr_t>(a->image)) & 15)
         return fail(SY_ERR_INVALID, "sy_mappo_ppo_grad: params and the image must be 16-byte aligned%s");
@@ -470,7 +471,7 @@ int sy_mappo_ppo_grad(const sy_ppo_args* a, void* stream) {
     k.image = a->image; k.image_rows = a->image_rows; k.row0 = a->row0; k.row0_dev = a->row0_dev; k.mb = a->num_rows;
     k.ell = a->ell; k.A = A; k.N = a->num_nodes; k.H = a->hidden;
     k.params = a->params;
-    k.clip = a->clip; k.value_coef = a->value_coef; k.partial = a->scratch; k.DN = 0; k.slab = 0; k.parts = 0; k.rpp = 0; k.adam_step = nullptr;
+    k.clip = a->clip; k.value_coef = a->value_coef; k.partial = a->scratch; k.DN = 0; k.slab = 0; k.parts = 0; k.rpp = 0; k.nroles = 0; k.adam_step = nullptr;
     sy::PpoAdam ad;
     ad.params = a->adam_m ? a->params : nullptr; ad.m = a->adam_m; ad.v = a->adam_v; ad.step = a->adam_step;
     ad.lr = a->lr; ad.beta1 = a->beta1; ad.beta2 = a->beta2; ad.eps = a->eps;

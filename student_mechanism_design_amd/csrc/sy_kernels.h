@@ -116,6 +116,9 @@ hipError_t launch_mappo_policy(const int32_t* pos, const uint8_t* mask, long lon
                                hipStream_t stream);
 
 // one PPO minibatch of the MAPPO networks: loss + gradient (sy_ppo.hip, sy_mappo_ppo_grad)
+#define SY_PPO_MAX_ROLES 64              // 2 (A + 1) networks' tables x row ranges
+#define SY_PPO_MAX_BLOCKS_PER_ROLE 96    // sizes the scratch of partial tables
+struct PpoGrid { int32_t parts, rpp, nroles; uint16_t first[SY_PPO_MAX_ROLES + 1]; };
 struct PpoPackArgs {     // rows of a rollout record -> the minibatch image (sy_ppo_pack)
     const int32_t* record; int32_t RW;
     const float* log_prob; const float* adv; const float* team_ret;
@@ -135,12 +138,14 @@ struct PpoArgs {
     float* partial;
     int32_t* adam_step;
     int32_t DN, slab, parts, rpp;     // filled by the launcher (parts: row ranges a table is cut into; rpp: rows per part)
+    int32_t nroles;
+    uint16_t first[SY_PPO_MAX_ROLES + 1];    // first block of every role (a role = one table part of one network); [nroles] = grid size
 };
 size_t ppo_image_size(int A, long long rows);
 hipError_t launch_ppo_pack(const PpoPackArgs& a, hipStream_t stream);
 int ppo_slab_floats(int N, int H);
 int ppo_parts(int N, int H);
-int ppo_blocks_per_role(int A, int N, int H);
+int ppo_max_blocks_per_role();
 struct PpoAdam {          // params == nullptr: no optimiser step
     float* params; float* m; float* v; int32_t* step;
     float lr, beta1, beta2, eps;

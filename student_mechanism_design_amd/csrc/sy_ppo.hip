@@ -162,13 +162,22 @@ template <int KP, int KEEP, bool WL>   // KP: 16-byte pieces of a hidden vector 
                                        // WL: the network's second-layer table (critic: its police block) is staged in LDS
 __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
     extern __shared__ double acc[];
+    // role index y = ((network * 2) + table) * parts + part: this block accumulates rows [n0, n1) of ONE table of one
+    // network.  Roles cost differently (the critic's police table takes P adds per row behind a short forward pass; MrX's
+    // actor has every entry affordable): the launcher gives each role a share of the grid in proportion (p.first[y] = its
+    // first block), so that all roles end together.
+#ifdef SY_PPO_DIAG_TIMES        // timing-only diagnostic: every block's start / end on the constant 100 MHz clock, in the tail of the scratch
+    const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+#endif
+    int y = 0;
+    while (y + 1 < p.nroles && (int)blockIdx.x >= p.first[y + 1]) ++y;
+    const int bx = (int)blockIdx.x - p.first[y], nbx = p.first[y + 1] - p.first[y];     // my index among the role's blocks
 #ifdef SY_PPO_DIAG_ONLY          // timing-only diagnostic: one role's blocks work, the others leave at once
-    if ((int)blockIdx.y != SY_PPO_DIAG_ONLY) return;
+    if (y != SY_PPO_DIAG_ONLY) return;
 #endif
     const int N = p.N, H = p.H, NH = N * H, A = p.A, P = A - 1;
-    // blockIdx.y = ((network * 2) + table) * parts + part: this block accumulates rows [n0, n1) of ONE table of one network
-    const int role = blockIdx.y / (2 * p.parts);                      // network: actor a < A, or the critic (A)
-    const int tab = (blockIdx.y / p.parts) & 1, part = blockIdx.y % p.parts;
+    const int role = y / (2 * p.parts);                               // network: actor a < A, or the critic (A)
+    const int tab = (y / p.parts) & 1, part = y % p.parts;
     const int n0 = part * p.rpp, n1 = min(N, n0 + p.rpp);
     double* const gT = acc;                              // table 0: d W1t[a] (critic: d C1m, the first layer's MrX block); table 1: d W2[a]
                                                          // (critic: d C1p, every police block's gradient); rows n0 .. n1 - 1, [H] each
@@ -200,11 +209,11 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
         pk[m] = pv[m] ? 4 * (j + 16 * m) : 0;
     }
     const ppo_f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
-    const int stride = gridDim.x * W * 4;
-    int i = (blockIdx.x * W + wave) * 4 + u;
+    const int stride = nbx * W * 4;
+    int i = (bx * W + wave) * 4 + u;
     const PpoImage im = ppo_image(p.image, A, p.image_rows);
     const int row0 = p.row0_dev ? *p.row0_dev : p.row0;        // (a device word: a captured graph replays on every minibatch)
-    if (p.adam_step && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *p.adam_step += 1;   // Adam's step count: read by the reduction launch
+    if (p.adam_step && blockIdx.x == 0 && threadIdx.x == 0) *p.adam_step += 1;   // Adam's step count: read by the reduction launch
     float loss = 0.0f;
     if (role < A) {
         // ---------------------------------------------------------------- actor `role`
@@ -460,7 +469,7 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
     if (smalls && j == 0) lds_add(gE, loss);
     __syncthreads();
     // this block's share of the network's slab [d table 0 (N*H) | d table 1 (N*H) | H | DN | 8]: every region has one owner
-    float* const dst = p.partial + ((size_t)blockIdx.x * (A + 1) + role) * p.slab;
+    float* const dst = p.partial + ((size_t)bx * (A + 1) + role) * p.slab;
     {
         float* const dt = dst + (size_t)tab * NH + (size_t)n0 * H;
         const int cnt = (n1 - n0) * H;
@@ -470,6 +479,14 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
         for (int k = threadIdx.x; k < H; k += blockDim.x) dst[2 * NH + k] = (float)gC[k];
     if (smalls)
         for (int k = threadIdx.x; k < p.DN + 8; k += blockDim.x) dst[2 * NH + H + k] = (float)gD[k];
+#ifdef SY_PPO_DIAG_TIMES
+    if (threadIdx.x == 0) {
+        unsigned long long* tw = reinterpret_cast<unsigned long long*>(p.partial + (size_t)(SY_PPO_MAX_BLOCKS_PER_ROLE - 1) * (A + 1) * p.slab);
+        tw[3 * blockIdx.x] = t_begin;
+        tw[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        tw[3 * blockIdx.x + 2] = (unsigned long long)y;
+    }
+#endif
 }
 
 // grads[t] = sum over the blocks of a role of their partial tables; with an optimiser state the Adam step of
@@ -477,10 +494,21 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
 // exp_avg_sq = b2 v + (1 - b2) g^2, param -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps).
 // The slab has slots that are not parameters (the loss sums, padding): they are left alone.  The critic's police table is
 // the SUM of its P blocks, every one of which takes the step: the sum moves P steps.
-__global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict__ partial, int nb, int total, float* __restrict__ out,
+__global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict__ partial, const PpoGrid gr, int total, float* __restrict__ out,
                                                          const PpoAdam ad, int A, int N, int H, int DN, int slab) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= total) return;
+    const int role = t / slab, off = t - role * slab, NH = N * H;
+    // the role that owns this word of the network's slab (ppo_grad_kernel's epilogue), and how many blocks it had
+    int tab, part = 0;
+    if (off < 2 * NH) {
+        tab = off >= NH ? 1 : 0;
+        part = ((off - tab * NH) / H) / gr.rpp;
+    } else {
+        tab = (role < A && off >= 2 * NH + H) ? 1 : 0;       // actor: b1 sums with table 0, b2 + loss with table 1; critic: all with table 0
+    }
+    const int y = (role * 2 + tab) * gr.parts + part;
+    const int nb = gr.first[y + 1] - gr.first[y];
     float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
     int b = 0;
     for (; b + 4 <= nb; b += 4) {
@@ -493,7 +521,7 @@ __global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict
     const float g = (s0 + s1) + (s2 + s3);
     out[t] = g;
     if (ad.params == nullptr) return;
-    const int role = t / slab, off = t - role * slab, NH = N * H, oE = 2 * NH + H + DN;
+    const int oE = 2 * NH + H + DN;
     const bool is_param = role < A ? off < 2 * NH + H + N : (off < 2 * NH + 2 * H || off == oE + 1);
     if (!is_param) return;
     const int step = *ad.step;                          // (advanced by the gradient launch)
@@ -531,11 +559,37 @@ static bool ppo_staged(int N, int H) {
     const int rpp = ppo_rows_per_part(N, H, true);
     return rpp >= 1 && (N + rpp - 1) / rpp == ppo_parts(N, H);
 }
-int ppo_blocks_per_role(int A, int N, int H) {
-    const int parts = ppo_parts(N, H);
-    const int nb = 256 / (2 * (A + 1) * (parts < 1 ? 1 : parts));    // one 1024-thread block per CU: 256 CUs
-    return nb < 1 ? 1 : nb;
+// The grid: every role's share of ~one block per CU, in proportion to what a pass over 64 rows costs it INSIDE a full launch
+// (block start / end stamps, -DSY_PPO_DIAG_TIMES, 200 nodes / hidden 64 / 4 police: MrX's W1t table 3.5 us, its W2 table
+// 5.4 — every row of MrX has a gradient and ~4 affordable entries —, a police actor's tables 5.1 / 4.7, the critic's MrX
+// block 1.7, its police block 4.5 = P adds per row).  With equal shares the launch waited for MrX's W2 table (148 us);
+// with these every role ends within 106-118 us (136 us per call).  One role's blocks timed ALONE run 1.3-3x faster per
+// pass than inside the full launch, and in a different order: alone-timings mislead here.
+static void ppo_grid(int A, int N, int H, int mb, PpoGrid& g) {
+    g.parts = ppo_parts(N, H);
+    g.rpp = (N + g.parts - 1) / g.parts;
+    g.nroles = 2 * (A + 1) * g.parts;
+    const int P = A - 1;
+    double w[SY_PPO_MAX_ROLES], tot = 0.0;
+    for (int y = 0; y < g.nroles; ++y) {
+        const int net = y / (2 * g.parts), tab = (y / g.parts) & 1;
+        w[y] = net == 0 ? (tab == 0 ? 0.65 : 1.0) : (net < A ? (tab == 0 ? 0.94 : 0.87) : (tab == 0 ? 0.31 : 0.21 * P));
+        tot += w[y];
+    }
+    const int budget = 256 > g.nroles ? 256 : g.nroles;                 // one 1024-thread block per CU: 256 CUs
+    const int need = (mb + 63) / 64;                                       // a 16-wave block takes 64 rows per pass
+    int used = 0;
+    g.first[0] = 0;
+    for (int y = 0; y < g.nroles; ++y) {
+        int nb = (int)(budget * w[y] / tot);
+        if (nb < 1) nb = 1;
+        if (nb > need) nb = need;
+        if (nb > SY_PPO_MAX_BLOCKS_PER_ROLE) nb = SY_PPO_MAX_BLOCKS_PER_ROLE;
+        used += nb;
+        g.first[y + 1] = used;
+    }
 }
+int ppo_max_blocks_per_role() { return SY_PPO_MAX_BLOCKS_PER_ROLE; }
 
 size_t ppo_image_size(int A, long long rows) { return ppo_image_bytes(A, rows); }
 
@@ -548,15 +602,14 @@ hipError_t launch_ppo_grad(PpoArgs a, float* grads, const PpoAdam& adam, hipStre
     a.adam_step = adam.params ? adam.step : nullptr;
     a.DN = ((a.N > a.H ? a.N : a.H) + 3) & ~3;
     a.slab = ppo_slab_floats(a.N, a.H);
-    a.parts = ppo_parts(a.N, a.H);
-    if (a.parts < 1) return hipErrorInvalidValue;
-    a.rpp = (a.N + a.parts - 1) / a.parts;           // balanced parts
+    if (ppo_parts(a.N, a.H) < 1 || 2 * (a.A + 1) * ppo_parts(a.N, a.H) > SY_PPO_MAX_ROLES) return hipErrorInvalidValue;
+    PpoGrid g;
+    ppo_grid(a.A, a.N, a.H, a.mb, g);
+    a.parts = g.parts; a.rpp = g.rpp; a.nroles = g.nroles;
+    for (int y = 0; y <= g.nroles; ++y) a.first[y] = g.first[y];
     const bool staged = ppo_staged(a.N, a.H);
-    int nb = ppo_blocks_per_role(a.A, a.N, a.H);
-    const int need = (a.mb + 63) / 64;          // a 16-wave block takes 64 rows per pass
-    if (nb > need) nb = need;
     const size_t lds = ((size_t)a.rpp * a.H + a.H + a.DN + 8) * sizeof(double) + (staged ? (size_t)a.N * a.H * sizeof(float) : 0);
-    const dim3 grid(nb, 2 * (a.A + 1) * a.parts);
+    const dim3 grid(g.first[g.nroles]);
     if (a.H <= 64) {
         if (staged) hipLaunchKernelGGL((ppo_grad_kernel<1, 0, true>), grid, dim3(1024), lds, stream, a);
         else hipLaunchKernelGGL((ppo_grad_kernel<1, 2, false>), grid, dim3(1024), lds, stream, a);
@@ -567,7 +620,7 @@ hipError_t launch_ppo_grad(PpoArgs a, float* grads, const PpoAdam& adam, hipStre
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     const int total = (a.A + 1) * a.slab;
-    hipLaunchKernelGGL(ppo_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, a.partial, nb, total, grads, adam, a.A, a.N, a.H,
+    hipLaunchKernelGGL(ppo_reduce_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, a.partial, g, total, grads, adam, a.A, a.N, a.H,
                        a.DN, a.slab);
     return hipGetLastError();
 }

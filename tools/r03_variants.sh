@@ -26,3 +26,7 @@ for g in ("8", "1", "64"):
 PY
 timeout -k 5 300 python tools/policy_rollout_bench.py > $O/policy_rollout_bench.log 2>&1; tail -8 $O/policy_rollout_bench.log
 timeout -k 5 300 python tools/collector_bench.py > $O/collector_bench.log 2>&1; tail -8 $O/collector_bench.log
+timeout -k 5 300 python tools/update_bench.py > $O/update_bench.log 2>&1; tail -6 $O/update_bench.log
+# per-kernel times of the fused PPO update (rocprofv3 kernel trace of 10 updates of 8 minibatches)
+R=$GRAFT_REPO_ROOT; (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/update_prof -- python3 $R/tools/update_bench.py "fused kernel, 8 minibatches, eager" > $R/$O/update_prof.log 2>&1)
+cp $(ls $O/update_prof/*/*kernel_stats.csv | head -1) $O/update_kernel_stats.csv && head -8 $O/update_kernel_stats.csv | cut -c1-160

@@ -48,7 +48,7 @@ def main():
     net = MappoPolicy(N, P, hidden_size=64).to(dev)
     fused = DeviceMappoPolicy(net, seed=0)
     env.set_policy(fused)
-    up = MappoUpdater(net, env.ell, env.env_graph, lr=args.lr, minibatch=args.minibatch, use_graph=True)
+    up = MappoUpdater(net, env.ell, env.env_graph, lr=args.lr, minibatch=args.minibatch)
     out = env.alloc_rollout(T)
     t_collect = t_update = 0.0
     for it in range(args.iters):

@@ -76,9 +76,15 @@ class MappoUpdater:
         self._fz = None
         self._env_graph32 = self.env_graph.to(torch.int32).contiguous()
         H = net.actors[0][0].out_features
-        fits = on_gpu and H % 4 == 0 and H <= 128
+        # (mirror of sy_ppo.hip's limits: a gradient table that does not fit the LDS is cut into row ranges, one role each,
+        # at most 64 roles = 2 tables x (A + 1) networks x ranges)
+        room = 160 * 1024 - (H + ((max(self.N, H) + 3) & ~3) + 8) * 8
+        rpp = min(self.N, room // (H * 8)) if H > 0 else 0
+        ranges = -(-self.N // rpp) if rpp >= 1 else 1 << 30
+        fits = on_gpu and H % 4 == 0 and H <= 128 and 2 * (self.A + 1) * ranges <= 64
         if fused and not fits:
-            raise ValueError("the fused PPO gradient kernel needs a GPU and hidden % 4 == 0, hidden <= 128")
+            raise ValueError("the fused PPO gradient kernel needs a GPU, hidden % 4 == 0, hidden <= 128 and nodes x hidden small "
+                             "enough for 64 table roles (e.g. 1024 nodes at hidden 64, 512 at 128 with 5 agents)")
         self.fused = fits if fused is None else bool(fused)
         self.H = H
 

@@ -442,3 +442,40 @@ def test_bench_starts_its_own_ranks_without_touching_the_gpu():
             "    print('RC', e.code, 'TORCH', 'torch' in sys.modules)\n" % os.path.join(ROOT, "bench.py"))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert "TORCH False" in out.stdout and "RC 0" not in out.stdout, (out.stdout, out.stderr[-500:])
+
+
+def test_ppo_gradient_abi_sizes_and_argument_checks():
+    """sy_ppo_pack / sy_mappo_ppo_grad (include/sy_env.h): the layout helpers agree with the host mirror, and bad arguments are
+    refused with a message before anything is launched (no GPU here: a launch would fail differently)."""
+    from student_mechanism_design_amd.update import MappoUpdater
+    L = sy._lib
+    lib = L.load()
+    for N, H in ((200, 64), (15, 8), (100, 128), (1024, 128)):
+        S = int(lib.sy_ppo_slab_floats(N, H))
+        assert S == MappoUpdater._slab_floats(N, H) == 2 * N * H + H + ((max(N, H) + 3) & ~3) + 8
+        assert int(lib.sy_ppo_scratch_floats(5, N, H)) % (6 * S) == 0
+    assert int(lib.sy_ppo_image_bytes(5, 1000)) == 1000 * (16 + 16 * 5 + 8)
+    buf = (C.c_float * 64)()
+    p = C.cast(buf, C.c_void_p)
+    pack = L.PpoPackArgs(p, 32, p, p, p, None, 0, 100, 8, p, 4, p, int(lib.sy_ppo_image_bytes(5, 100)), 0, 0)
+    for field, value, needle in (("image", None, "null"), ("num_police", 0, "bad sizes"), ("record_words", 8, "record_words"),
+                                 ("image_bytes", 16, "image too small"), ("shuffle_domain", 50, "shuffle_domain")):
+        a = L.PpoPackArgs.from_buffer_copy(pack)
+        setattr(a, field, value)
+        assert lib.sy_ppo_pack(C.byref(a), None) == -1
+        assert needle in lib.sy_last_error().decode(), (field, lib.sy_last_error())
+    a = L.PpoPackArgs.from_buffer_copy(pack)
+    a.rows, a.shuffle_domain = p, 100
+    assert lib.sy_ppo_pack(C.byref(a), None) == -1 and "not both" in lib.sy_last_error().decode()
+    grad = L.PpoArgs(p, 100, 0, None, 100, p, 4, 200, 64, p, 0.2, 0.5, p, int(lib.sy_ppo_scratch_floats(5, 200, 64)), p, None, None, None,
+                     3e-4, 0.9, 0.999, 1e-8)
+    for field, value, needle in (("params", None, "null"), ("hidden", 66, "multiple of 4"), ("hidden", 132, "multiple of 4"),
+                                 ("scratch_floats", 10, "scratch too small"), ("num_rows", 101, "past the image"),
+                                 ("num_nodes", 1, "bad sizes"), ("adam_m", p, "go together")):
+        a = L.PpoArgs.from_buffer_copy(grad)
+        setattr(a, field, value)
+        assert lib.sy_mappo_ppo_grad(C.byref(a), None) == -1
+        assert needle in lib.sy_last_error().decode(), (field, lib.sy_last_error())
+    a = L.PpoArgs.from_buffer_copy(grad)
+    a.adam_m, a.adam_v, a.adam_step, a.lr = p, p, p, 0.0
+    assert lib.sy_mappo_ppo_grad(C.byref(a), None) == -1 and "Adam constants" in lib.sy_last_error().decode()

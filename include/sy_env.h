@@ -330,6 +330,9 @@ typedef struct sy_ppo_pack_args {
     int64_t image_bytes;
     int64_t shuffle_domain;   /* rows == NULL and > 0: image row i <- record row row0 + pi(i), pi a pseudo-random permutation of */
     uint64_t shuffle_seed;    /* [0, shuffle_domain) keyed by the seed (a 4-round Feistel network, cycle-walked: no sort)       */
+    int64_t chunk_rows;       /* > 0: `record` and `log_prob` are CHUNKS of chunk_rows rows each (the arenas of several ranks after */
+    int64_t record_chunk_stride, log_prob_chunk_stride;   /* the one all-gather of an update), chunk c at c * stride elements;      */
+                              /* adv / team_ret stay plain [R] arrays; 0: one contiguous array each                                */
 } sy_ppo_pack_args;
 int64_t sy_ppo_image_bytes(int32_t num_agents, int64_t num_rows);
 int sy_ppo_pack(const sy_ppo_pack_args *args, void *stream);
@@ -354,6 +357,11 @@ typedef struct sy_ppo_args {
 int32_t sy_ppo_slab_floats(int32_t num_nodes, int32_t hidden);
 int64_t sy_ppo_scratch_floats(int32_t num_agents, int32_t num_nodes, int32_t hidden);
 int sy_mappo_ppo_grad(const sy_ppo_args *args, void *stream);
+/* the Adam step of sy_mappo_ppo_grad on its own, for data-parallel training: call sy_mappo_ppo_grad WITHOUT an optimiser
+ * state, all-reduce (average) `grads` [A + 1][S] across the ranks, then take the step here (the optim.Adam lines of
+ * agent/mappo_agent.py:80-83,265,293); same slab layout, same rule, adam_step advanced by one */
+int sy_ppo_adam_step(float *params, const float *grads, float *adam_m, float *adam_v, int32_t *adam_step, int32_t num_police,
+                     int32_t num_nodes, int32_t hidden, float lr, float beta1, float beta2, float eps, void *stream);
 
 /* replaces Pathfinder.get_distance (pathfinding.py:34-137) for a whole pool: all-pairs weighted
  * shortest paths from the ELL table, apsp uint16 [G][N][N] (0xFFFF = unreachable); all device */

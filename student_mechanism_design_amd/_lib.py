@@ -52,7 +52,8 @@ class PpoPackArgs(C.Structure):
     _fields_ = [("record", C.c_void_p), ("record_words", C.c_int32), ("log_prob", C.c_void_p), ("adv", C.c_void_p),
                 ("team_ret", C.c_void_p), ("rows", C.c_void_p), ("row0", C.c_int32), ("num_rows", C.c_int64),
                 ("num_envs", C.c_int32), ("env_graph", C.c_void_p), ("num_police", C.c_int32), ("image", C.c_void_p),
-                ("image_bytes", C.c_int64), ("shuffle_domain", C.c_int64), ("shuffle_seed", C.c_uint64)]
+                ("image_bytes", C.c_int64), ("shuffle_domain", C.c_int64), ("shuffle_seed", C.c_uint64), ("chunk_rows", C.c_int64),
+                ("record_chunk_stride", C.c_int64), ("log_prob_chunk_stride", C.c_int64)]
 
 
 class PpoArgs(C.Structure):
@@ -74,7 +75,7 @@ EXPORTS = ["sy_abi_version", "sy_record_words", "sy_last_error", "sy_env_create"
            "sy_masked_categorical_sample", "sy_mappo_policy_act", "sy_env_bind_status", "sy_env_status",
            "sy_returns_advantages", "sy_build_id", "sy_env_rollout_kernel_name",
            "sy_gnn_padded_features", "sy_gnn_param_floats", "sy_gnn_q_act",
-           "sy_ppo_slab_floats", "sy_ppo_scratch_floats", "sy_mappo_ppo_grad", "sy_ppo_image_bytes", "sy_ppo_pack"]
+           "sy_ppo_slab_floats", "sy_ppo_scratch_floats", "sy_mappo_ppo_grad", "sy_ppo_image_bytes", "sy_ppo_pack", "sy_ppo_adam_step"]
 
 _lib = None
 
@@ -125,6 +126,7 @@ def load():
     lib.sy_mappo_ppo_grad.argtypes = [C.POINTER(PpoArgs), vp]
     lib.sy_ppo_image_bytes.argtypes = [i32, C.c_int64]
     lib.sy_ppo_pack.argtypes = [C.POINTER(PpoPackArgs), vp]
+    lib.sy_ppo_adam_step.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, C.c_float, C.c_float, C.c_float, C.c_float, vp]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("sy_last_error", "sy_build_id"):

@@ -435,6 +435,10 @@ int sy_ppo_pack(const sy_ppo_pack_args* a, void* stream) {
     k.record = a->record; k.RW = a->record_words; k.log_prob = a->log_prob; k.adv = a->adv; k.team_ret = a->team_ret;
     k.rows = a->rows; k.row0 = a->row0; k.count = a->num_rows; k.B = a->num_envs; k.env_graph = a->env_graph; k.A = A;
     k.image = a->image;
+    k.chunk_rows = a->chunk_rows; k.record_chunk_stride = a->record_chunk_stride; k.log_prob_chunk_stride = a->log_prob_chunk_stride;
+    if (a->chunk_rows < 0 || (a->chunk_rows > 0 && (a->record_chunk_stride < a->chunk_rows * (int64_t)a->record_words ||
+                                                   a->log_prob_chunk_stride < a->chunk_rows * (int64_t)A)))
+        return fail(SY_ERR_INVALID, "sy_ppo_pack: chunk strides smaller than a chunk%s");
     k.shuffle_domain = 0; k.shuffle_hb = 0; k.shuffle_seed = a->shuffle_seed;
     if (a->shuffle_domain != 0) {
         if (a->rows) return fail(SY_ERR_INVALID, "sy_ppo_pack: give `rows` or a shuffle, not both%s");
@@ -477,6 +481,20 @@ int sy_mappo_ppo_grad(const sy_ppo_args* a, void* stream) {
     ad.lr = a->lr; ad.beta1 = a->beta1; ad.beta2 = a->beta2; ad.eps = a->eps;
     hipError_t e = sy::launch_ppo_grad(k, a->grads, ad, (hipStream_t)stream);
     return e == hipSuccess ? SY_OK : hip_fail(e, "sy_mappo_ppo_grad launch");
+}
+
+int sy_ppo_adam_step(float* params, const float* grads, float* adam_m, float* adam_v, int32_t* adam_step, int32_t num_police,
+                     int32_t num_nodes, int32_t hidden, float lr, float beta1, float beta2, float eps, void* stream) {
+    if (!params || !grads || !adam_m || !adam_v || !adam_step) return fail(SY_ERR_INVALID, "sy_ppo_adam_step: null argument%s");
+    const int A = num_police + 1;
+    if (num_police < 1 || A > SY_MAX_AGENTS || num_nodes < 2 || num_nodes > SY_MAX_NODES || hidden < 4 || (hidden & 3) || hidden > 128)
+        return fail(SY_ERR_INVALID, "sy_ppo_adam_step: bad sizes%s");
+    if (!(lr > 0.0f) || !(beta1 >= 0.0f && beta1 < 1.0f) || !(beta2 >= 0.0f && beta2 < 1.0f) || !(eps > 0.0f))
+        return fail(SY_ERR_INVALID, "sy_ppo_adam_step: bad Adam constants%s");
+    sy::PpoAdam ad;
+    ad.params = params; ad.m = adam_m; ad.v = adam_v; ad.step = adam_step; ad.lr = lr; ad.beta1 = beta1; ad.beta2 = beta2; ad.eps = eps;
+    hipError_t e = sy::launch_ppo_adam(grads, ad, A, num_nodes, hidden, (hipStream_t)stream);
+    return e == hipSuccess ? SY_OK : hip_fail(e, "sy_ppo_adam_step launch");
 }
 
 int sy_build_apsp(const uint32_t* ell, int32_t num_nodes, int32_t num_graphs, uint16_t* apsp, void* stream) {

@@ -126,6 +126,7 @@ struct PpoPackArgs {     // rows of a rollout record -> the minibatch image (sy_
     const int32_t* env_graph;
     int32_t A;
     void* image;
+    long long chunk_rows, record_chunk_stride, log_prob_chunk_stride;   // chunk_rows > 0: record / log_prob are chunks of that many rows, strides in elements
     long long shuffle_domain; int32_t shuffle_hb; uint64_t shuffle_seed;    // rows == nullptr, domain > 0: row0 + permutation(i) of [0, domain)
 };
 struct PpoArgs {
@@ -151,6 +152,7 @@ struct PpoAdam {          // params == nullptr: no optimiser step
     float lr, beta1, beta2, eps;
 };
 hipError_t launch_ppo_grad(PpoArgs a, float* grads, const PpoAdam& adam, hipStream_t stream);
+hipError_t launch_ppo_adam(const float* grads, const PpoAdam& ad, int A, int N, int H, hipStream_t stream);
 
 // the GNN Q-policy (sy_gnn.hip)
 int gnn_padded_features(int F);

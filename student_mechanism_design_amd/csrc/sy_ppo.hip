@@ -142,7 +142,15 @@ __global__ __launch_bounds__(256) void ppo_pack_kernel(const PpoPackArgs p) {
     long long r = p.rows ? (long long)p.rows[i] : (long long)p.row0 + i;
     if (!p.rows && p.shuffle_domain > 0)
         r = (long long)p.row0 + ppo_shuffle((uint32_t)i, (uint32_t)p.shuffle_domain, p.shuffle_hb, (uint32_t)p.shuffle_seed, (uint32_t)(p.shuffle_seed >> 32));
-    const int32_t* const rec = p.record + (size_t)r * p.RW;
+    // chunked records (the arenas of several ranks after the all-gather, one chunk per rank): row r = chunk r / chunk_rows
+    size_t rec_off = (size_t)r * p.RW, lp_off = (size_t)r * A;
+    if (p.chunk_rows > 0) {
+        const long long ch = r / p.chunk_rows, rr = r - ch * p.chunk_rows;
+        rec_off = (size_t)ch * p.record_chunk_stride + (size_t)rr * p.RW;
+        lp_off = (size_t)ch * p.log_prob_chunk_stride + (size_t)rr * A;
+    }
+    const int32_t* const rec = p.record + rec_off;
+    const float* const lp = p.log_prob + lp_off;
     char* const base = reinterpret_cast<char*>(p.image);
     uint16_t* const posq = reinterpret_cast<uint16_t*>(base) + (size_t)i * 8;
     int4* const agent = reinterpret_cast<int4*>(base + (size_t)p.count * 16);
@@ -152,7 +160,7 @@ __global__ __launch_bounds__(256) void ppo_pack_kernel(const PpoPackArgs p) {
     for (int k = 0; k < 8; ++k) q[k] = k < A ? (uint16_t)rec[2 * A + k] : (uint16_t)0;
     *reinterpret_cast<uint4*>(posq) = *reinterpret_cast<const uint4*>(q);
     for (int k = 0; k < A; ++k)
-        agent[(size_t)k * p.count + i] = make_int4(rec[3 * A + k], rec[4 * A + k], __float_as_int(p.log_prob[(size_t)r * A + k]),
+        agent[(size_t)k * p.count + i] = make_int4(rec[3 * A + k], rec[4 * A + k], __float_as_int(lp[k]),
                                                    __float_as_int(p.adv[(size_t)r * A + k]));
     tail[i] = make_int2(__float_as_int(p.team_ret[r]), p.env_graph[r % p.B]);
 }
@@ -535,7 +543,35 @@ __global__ __launch_bounds__(256) void ppo_reduce_kernel(const float* __restrict
     ad.params[t] -= scale * (ad.lr / bc1) * (m / denom);
 }
 
+// The Adam step alone, on a gradient slab that is already summed (data-parallel training: the ranks' slabs are all-reduced
+// between the gradient launch and this one).  Same rule as the fused form above.
+__global__ __launch_bounds__(256) void ppo_adam_kernel(const float* __restrict__ grads, int total, const PpoAdam ad, int A, int N, int H,
+                                                       int DN, int slab) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    const int role = t / slab, off = t - role * slab, NH = N * H, oE = 2 * NH + H + DN;
+    const bool is_param = role < A ? off < 2 * NH + H + N : (off < 2 * NH + 2 * H || off == oE + 1);
+    if (!is_param) return;
+    const float g = grads[t];
+    const int step = *ad.step;                          // (advanced by ppo_adam_tick_kernel, the launch before)
+    const float bc1 = 1.0f - powf(ad.beta1, (float)step), bc2 = 1.0f - powf(ad.beta2, (float)step);
+    const float m = ad.beta1 * ad.m[t] + (1.0f - ad.beta1) * g;
+    const float v = ad.beta2 * ad.v[t] + (1.0f - ad.beta2) * g * g;
+    ad.m[t] = m;
+    ad.v[t] = v;
+    const float denom = sqrtf(v) / sqrtf(bc2) + ad.eps;
+    const float scale = (role == A && off >= NH && off < 2 * NH) ? (float)(A - 1) : 1.0f;
+    ad.params[t] -= scale * (ad.lr / bc1) * (m / denom);
+}
+__global__ void ppo_adam_tick_kernel(int32_t* step) { *step += 1; }
+
 // ---- launchers
+hipError_t launch_ppo_adam(const float* grads, const PpoAdam& ad, int A, int N, int H, hipStream_t stream) {
+    const int DN = ((N > H ? N : H) + 3) & ~3, slab = ppo_slab_floats(N, H), total = (A + 1) * slab;
+    hipLaunchKernelGGL(ppo_adam_tick_kernel, dim3(1), dim3(1), 0, stream, ad.step);
+    hipLaunchKernelGGL(ppo_adam_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, grads, total, ad, A, N, H, DN, slab);
+    return hipGetLastError();
+}
 int ppo_slab_floats(int N, int H) {
     const int dn = ((N > H ? N : H) + 3) & ~3;
     return 2 * N * H + H + dn + 8;

@@ -58,10 +58,13 @@ class _OneHotLinear(torch.autograd.Function):
 class MappoUpdater:
     def __init__(self, net: MappoPolicy, ell: torch.Tensor, env_graph: torch.Tensor, lr: float = 3e-4, clip: float = 0.2,
                  minibatch: int = 32768, value_coef: float = 0.5, use_graph: bool = False, mrx_money: int = 1000,
-                 fused: Optional[bool] = None):
+                 fused: Optional[bool] = None, grad_sync=None):
         """ell int32 [G, N, 16] (the engine's board table: neighbour | weight << 16), env_graph int [B].
         fused: None = the HIP gradient kernel when it applies (GPU, hidden a multiple of 4 up to 128);
-        True = require it (raises otherwise); False = the torch form."""
+        True = require it (raises otherwise); False = the torch form.
+        grad_sync: data-parallel training on the fused path — a callable that receives the minibatch's gradient slab
+        [A + 1, S] (summed over THIS rank's rows) and averages it across the ranks in place, e.g.
+        `collector.allreduce_slab`; the Adam step then runs as its own launch on the averaged gradient."""
         self.net, self.clip, self.minibatch, self.value_coef = net, float(clip), int(minibatch), float(value_coef)
         self.device = next(net.parameters()).device
         self.ell = ell.to(self.device)
@@ -74,6 +77,7 @@ class MappoUpdater:
         self._graph, self._static = None, None
         self.last_losses = None
         self._fz = None
+        self.grad_sync = grad_sync
         self._env_graph32 = self.env_graph.to(torch.int32).contiguous()
         H = net.actors[0][0].out_features
         # (mirror of sy_ppo.hip's limits: a gradient table that does not fit the LDS is cut into row ranges, one role each,
@@ -206,24 +210,53 @@ class MappoUpdater:
         sy_mappo_ppo_grad = the gradient launch + the reduction that takes the Adam step on the resident parameters."""
         ptr = lambda t: C.c_void_p(t.data_ptr())                                   # noqa: E731
         b1, b2 = self.opt.param_groups[0]["betas"]
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        if self.grad_sync is not None:                  # gradient launch, the ranks' slabs averaged, then the Adam launch
+            args = z["_lib"].PpoArgs(ptr(z["image"]), int(z["image_rows"]), int(row0), ptr(z["row0"]) if self.use_graph else None,
+                                     int(num_rows), ptr(self.ell), self.P, self.N, self.H, ptr(z["theta"]), self.clip, self.value_coef,
+                                     ptr(z["scratch"]), int(z["scratch"].numel()), ptr(z["grads"]), None, None, None,
+                                     float(self.opt.param_groups[0]["lr"]), float(b1), float(b2), float(self.opt.param_groups[0]["eps"]))
+            z["_lib"].check(z["lib"].sy_mappo_ppo_grad(C.byref(args), stream), "sy_mappo_ppo_grad")
+            self.grad_sync(z["grads"])
+            z["_lib"].check(z["lib"].sy_ppo_adam_step(ptr(z["theta"]), ptr(z["grads"]), ptr(z["m"]), ptr(z["v"]), ptr(z["step"]), self.P,
+                                                      self.N, self.H, float(self.opt.param_groups[0]["lr"]), float(b1), float(b2),
+                                                      float(self.opt.param_groups[0]["eps"]), stream), "sy_ppo_adam_step")
+            return
         args = z["_lib"].PpoArgs(ptr(z["image"]), int(z["image_rows"]), int(row0), ptr(z["row0"]) if self.use_graph else None,
                                  int(num_rows), ptr(self.ell), self.P, self.N, self.H, ptr(z["theta"]), self.clip, self.value_coef,
                                  ptr(z["scratch"]), int(z["scratch"].numel()), ptr(z["grads"]), ptr(z["m"]), ptr(z["v"]), ptr(z["step"]),
                                  float(self.opt.param_groups[0]["lr"]), float(b1), float(b2), float(self.opt.param_groups[0]["eps"]))
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         z["_lib"].check(z["lib"].sy_mappo_ppo_grad(C.byref(args), stream), "sy_mappo_ppo_grad")
 
+    @staticmethod
+    def _chunks(t, inner):
+        """(rows per chunk, chunk stride in elements) of a [..., B, inner] view whose trailing [T, B, inner] block is
+        contiguous: one chunk if the whole view is, else one chunk per index of the leading dim (the per-rank arenas of
+        `TrajectoryExchange.gather`: [world, T, B, inner], contiguous inside a rank, `nbytes` apart between ranks)."""
+        if t.is_contiguous():
+            return 0, 0
+        if t.dim() >= 3 and t[0].is_contiguous() and t.stride(0) >= t[0].numel():
+            return t[0].numel() // inner, t.stride(0)
+        raise ValueError("the fused update reads the record in place: it must be contiguous, or a stack of contiguous per-rank records")
+
     def _update_fused(self, rec, returns, values, generator):
-        T, B, A = rec["action"].shape
-        R = T * B
+        A = rec["action"].shape[-1]
+        B = rec["action"].shape[-2]
+        R = rec["action"].numel() // A                                           # rows = (ranks x) T x B
         mb = min(self.minibatch, R)
         nfull = R // mb                                                           # (a ragged tail is dropped, as minibatch PPO does)
-        record = rec["record"]
-        if record.dtype != torch.int32 or not record.is_contiguous() or record.shape[:2] != (T, B):
-            raise ValueError("the fused update reads the packed rollout record: rec['record'] must be the contiguous int32 [T, B, RW] tensor")
+        record, log_prob = rec["record"], rec["log_prob"]
+        if record.dtype != torch.int32 or log_prob.dtype != torch.float32 or record.shape[:-1] != rec["action"].shape[:-1]:
+            raise ValueError("the fused update reads the packed rollout record: rec['record'] int32 [..., T, B, RW], rec['log_prob'] float32")
+        RW = int(record.shape[-1])
+        rec_chunk, rec_stride = self._chunks(record, RW)
+        lp_chunk, lp_stride = self._chunks(log_prob, A)
+        if (rec_chunk == 0) != (lp_chunk == 0) or (rec_chunk and rec_chunk != lp_chunk):
+            log_prob, lp_chunk, lp_stride = log_prob.contiguous(), 0, 0
+            if rec_chunk:
+                record, rec_chunk, rec_stride = record.contiguous(), 0, 0
         adv = returns if values is None else returns - values.unsqueeze(-1)
         adv = ((adv - adv.mean()) / (adv.std() + 1e-8)).float().contiguous()      # mappo_agent.py:256-258
-        log_prob = rec["log_prob"].float().contiguous()
         team_ret = returns.sum(-1).float().contiguous()
         if self.ell.dtype != torch.int32 or not self.ell.is_contiguous():
             self.ell = self.ell.to(torch.int32).contiguous()
@@ -248,8 +281,9 @@ class MappoUpdater:
         if generator is not None:
             seed = (int(base) * 0x9E3779B97F4A7C15 + 0x85EBCA6B) & (2 ** 64 - 1)   # an explicit generator decides alone (reproducible)
         ptr = lambda t: C.c_void_p(t.data_ptr())                                   # noqa: E731
-        pargs = _lib.PpoPackArgs(ptr(record), int(record.shape[-1]), ptr(log_prob), ptr(adv), ptr(team_ret), None, 0, rows, B,
-                                 ptr(self._env_graph32), self.P, ptr(z["image"]), int(z["image"].numel()), R, seed)
+        pargs = _lib.PpoPackArgs(ptr(record), RW, ptr(log_prob), ptr(adv), ptr(team_ret), None, 0, rows, B,
+                                 ptr(self._env_graph32), self.P, ptr(z["image"]), int(z["image"].numel()), R, seed,
+                                 int(rec_chunk), int(rec_stride), int(lp_stride))
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(lib.sy_ppo_pack(C.byref(pargs), stream), "sy_ppo_pack")
         if self.use_graph and self._graph is not None and self._graph_key != (z["image"].data_ptr(), mb):

@@ -177,6 +177,10 @@ def _worker_arena(rank, world, port, q):
                     # views of the receive buffer, not copies
                     ok = ok and recv_ptr <= out[k].data_ptr() < recv_ptr + ex._recv.numel()
             ok = ok and out["pos"].shape[:2] == (world, 4)
+        # the data-parallel alternative: the fused update's gradient slab averaged across the ranks, in place, one collective
+        slab = torch.full((4, 10), float(rank + 1))
+        back = col.allreduce_slab(slab)
+        ok = ok and back is slab and bool((slab == (1 + world) / 2).all())
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
@@ -217,6 +221,8 @@ def test_arena_record_layout_and_single_rank_gather():
 
 
 def test_allreduce_gradients_is_identity_without_a_group():
+    slab = torch.arange(6.0).view(2, 3)
+    assert col.allreduce_slab(slab) is slab and torch.equal(slab, torch.arange(6.0).view(2, 3))
     lin = torch.nn.Linear(3, 2)
     lin(torch.ones(1, 3)).sum().backward()
     g = lin.weight.grad.clone()

@@ -1157,3 +1157,78 @@ def test_ppo_pack_shuffle_is_a_permutation(sy, R, rows):
         np.testing.assert_array_equal(_np(agent[a, :, 3].view(torch.float32)), _np(adv[src][:, a]))
     src2 = pack(54321)[2][:, 0].view(torch.float32).long()
     assert int((src2 == src).sum()) < rows // 4
+
+
+def test_fused_ppo_update_reads_gathered_trajectories_in_place(sy):
+    """After the ONE all-gather of an update every rank holds [world, T, B, ...] views of per-rank arenas
+    (`TrajectoryExchange.gather`): contiguous inside a rank, an arena apart between ranks.  `sy_ppo_pack` addresses such
+    chunks in place; the update on the views equals the update on a contiguous copy of the same rows."""
+    import copy
+    from student_mechanism_design_amd import collector as col, policies as pol
+    from student_mechanism_design_amd.env import RolloutRecord, record_fields
+    from student_mechanism_design_amd.update import MappoUpdater
+    N, P, H, B, T = 90, 4, 64, 48, 10
+    boards = sy.sample_board_pool(2, N, 170, seed=9)
+    env = sy.BatchedScotlandYardEnv(B, boards, P, 9, np.full(11, 0.5), seed=11, reveal_interval=3)
+    torch.manual_seed(3)
+    net_a = pol.MappoPolicy(N, P, hidden_size=H).to(env.device)
+    net_b = copy.deepcopy(net_a)
+    env.set_policy(pol.DeviceMappoPolicy(net_a, seed=2))
+    recs = [env.rollout(T) for _ in range(2)]                                   # "two ranks"
+    torch.cuda.synchronize()
+    rets = [col.device_returns(r["reward"], r["terminated"], 0.99, done_b=r["truncated"])[0] for r in recs]
+    recv = torch.stack([r.arena for r in recs])                                 # [world, nbytes], as all_gather_into_tensor leaves it
+    gathered = RolloutRecord.views_of(recv, recs[0].layout, lead=(2,))
+    gathered.update(record_fields(gathered["record"], P + 1))
+    assert not gathered["record"].is_contiguous() and gathered["record"].shape == (2, T, B, recs[0]["record"].shape[-1])
+    flat = {"record": torch.cat([r["record"] for r in recs]), "log_prob": torch.cat([r["log_prob"] for r in recs])}
+    flat.update(record_fields(flat["record"], P + 1))
+    up_a = MappoUpdater(net_a, env.ell, env.env_graph, minibatch=2 * T * B // 2, fused=True, lr=1e-3)
+    up_b = MappoUpdater(net_b, env.ell, env.env_graph, minibatch=2 * T * B // 2, fused=True, lr=1e-3)
+    gen = torch.Generator(device=env.device)
+    la = up_a.update(gathered, torch.stack(rets), generator=gen.manual_seed(5))
+    lb = up_b.update(flat, torch.cat(rets), generator=gen.manual_seed(5))
+    np.testing.assert_allclose([float(x) for x in la], [float(x) for x in lb], rtol=1e-5, atol=1e-7)
+    for pa, pb in zip(net_a.parameters(), net_b.parameters()):
+        np.testing.assert_allclose(_np(pa), _np(pb), rtol=0, atol=1e-6)
+    env.close()
+
+
+def test_fused_ppo_update_with_a_gradient_exchange_between_the_launches(sy):
+    """`grad_sync` (data-parallel training): gradient launch, the hook on the slab, then `sy_ppo_adam_step`.  With an
+    identity hook the parameters equal the fused form's (Adam inside the reduction launch) update after update; a hook that
+    zeroes the slab leaves them where they were (the exchange itself, `collector.allreduce_slab`, is covered by the gloo
+    world-2 test on the CPU)."""
+    import copy
+    from student_mechanism_design_amd import collector as col, policies as pol
+    from student_mechanism_design_amd.update import MappoUpdater
+    N, P, H, B, T = 70, 3, 32, 40, 12
+    boards = sy.sample_board_pool(2, N, 130, seed=21)
+    env = sy.BatchedScotlandYardEnv(B, boards, P, 9, np.full(11, 0.5), seed=23, reveal_interval=3)
+    torch.manual_seed(7)
+    net0 = pol.MappoPolicy(N, P, hidden_size=H).to(env.device)
+    env.set_policy(pol.DeviceMappoPolicy(net0, seed=2))
+    rec = env.rollout(T)
+    ret, _ = col.device_returns(rec["reward"], rec["terminated"], 0.99, done_b=rec["truncated"])
+    R = T * B
+    calls = []
+
+    def identity(g):
+        calls.append(tuple(g.shape))
+        return g
+
+    nets = [copy.deepcopy(net0) for _ in range(3)]
+    up_f = MappoUpdater(nets[0], env.ell, env.env_graph, minibatch=R // 2, fused=True, lr=1e-3)
+    up_i = MappoUpdater(nets[1], env.ell, env.env_graph, minibatch=R // 2, fused=True, lr=1e-3, grad_sync=identity)
+    up_z = MappoUpdater(nets[2], env.ell, env.env_graph, minibatch=R // 2, fused=True, lr=1e-3, grad_sync=lambda g: g.zero_())
+    gen = torch.Generator(device=env.device)
+    for it in range(2):
+        up_f.update(rec, ret, generator=gen.manual_seed(it))
+        up_i.update(rec, ret, generator=gen.manual_seed(it))
+        up_z.update(rec, ret, generator=gen.manual_seed(it))
+    assert len(calls) == 4 and calls[0] == (P + 2, up_i._fz["S"])
+    for pf, pi, pz, p0 in zip(nets[0].parameters(), nets[1].parameters(), nets[2].parameters(), net0.parameters()):
+        np.testing.assert_allclose(_np(pi), _np(pf), rtol=0, atol=1e-6)
+        np.testing.assert_allclose(_np(pz), _np(p0), rtol=0, atol=1e-7)
+        assert bool((pf != p0).any())
+    env.close()

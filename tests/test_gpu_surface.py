@@ -1032,7 +1032,8 @@ def test_in_kernel_policy_underflow_rule_and_hidden_128(sy):
 
 
 @pytest.mark.parametrize("N,P,H,B,T", [(200, 4, 64, 96, 24), (60, 3, 32, 50, 16), (100, 6, 128, 40, 12), (24, 2, 8, 33, 20), (150, 7, 64, 21, 10),
-                                       (200, 4, 128, 48, 8)])      # (the last: a table larger than the LDS, two row ranges)
+                                       (200, 4, 128, 48, 8),       # (a table larger than the LDS, two row ranges)
+                                       (12, 1, 4, 7, 5)])          # (one officer, hidden 4, 35 rows: less than one pass of a block)
 def test_fused_ppo_gradient_matches_the_torch_form(sy, N, P, H, B, T):
     """sy_mappo_ppo_grad (loss + gradient of a PPO minibatch in one HIP kernel, LDS-resident gradient tables) against the
     torch restatement of MappoAgent.ppo_update (update.py::_losses + autograd) on a recorded policy rollout: both losses and

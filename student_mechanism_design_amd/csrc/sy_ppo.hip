@@ -23,6 +23,8 @@
 // rows -> W2 rows): the first two hops are prefetched one iteration ahead, the W2 rows of four entries are in flight
 // together, and 16 waves per CU overlap the rest.  Summation order differs from a BLAS matmul: parity with the torch form
 // is to float32 rounding (tests: 1e-4 relative on every gradient).
+#include <type_traits>
+
 #include "sy_device.hpp"
 
 namespace sy {
@@ -165,9 +167,13 @@ __global__ __launch_bounds__(256) void ppo_pack_kernel(const PpoPackArgs p) {
     tail[i] = make_int2(__float_as_int(p.team_ret[r]), p.env_graph[r % p.B]);
 }
 
-template <int KP, int KEEP, bool WL>   // KP: 16-byte pieces of a hidden vector per lane, 1 (hidden <= 64) or 2 (<= 128);
-                                       // KEEP: rounds of four W2 rows kept in registers for the backward pass;
-                                       // WL: the network's second-layer table (critic: its police block) is staged in LDS
+#ifdef SY_PPO_DIAG_TIMES
+#define PPO_STAMP(k) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[k] += (unsigned)(tn - tl); tl = tn; }
+#else
+#define PPO_STAMP(k)
+#endif
+template <int KP, bool WL>   // KP: 16-byte pieces of a hidden vector per lane, 1 (hidden <= 64) or 2 (<= 128);
+                             // WL: the network's second-layer table (critic: its police block) is staged in LDS
 __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
     extern __shared__ double acc[];
     // role index y = ((network * 2) + table) * parts + part: this block accumulates rows [n0, n1) of ONE table of one
@@ -176,6 +182,8 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
     // first block), so that all roles end together.
 #ifdef SY_PPO_DIAG_TIMES        // timing-only diagnostic: every block's start / end on the constant 100 MHz clock, in the tail of the scratch
     const unsigned long long t_begin = __builtin_amdgcn_s_memrealtime();
+    unsigned ph[5] = {0, 0, 0, 0, 0};
+    unsigned long long tl = __builtin_amdgcn_s_memtime();
 #endif
     int y = 0;
     while (y + 1 < p.nroles && (int)blockIdx.x >= p.first[y + 1]) ++y;
@@ -245,6 +253,7 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
         }
         PpoRow nx = ppo_fetch_row<true>(p, im, row0, i, a, j);
         for (; __builtin_amdgcn_readfirstlane(i - u) < p.mb; i += stride) {
+            PPO_STAMP(4)
             const PpoRow rw = nx;
             const int node_a = __shfl(rw.posv, a, 16);
             // the agent's ELL row: lane j holds entry j; affordable entries compacted to lanes 0 .. n - 1 of the group
@@ -261,6 +270,7 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
             }
 #pragma unroll
             for (int m = 0; m < KP; ++m) h[m] = relu4(z[m]);
+            PPO_STAMP(0)
             const bool legal = rw.on && (int)(ent >> 16) <= rw.bud;
             const uint32_t L = (uint32_t)(bal(legal) >> (16 * u)) & 0xffffu;
             const int n = __popc(L);
@@ -277,40 +287,36 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
 #else
             const int nmax = __builtin_amdgcn_readfirstlane(max(max(__shfl(n, 0), __shfl(n, 16)), max(__shfl(n, 32), __shfl(n, 48))));
 #endif
-            // logits: entry e of every group per step, four steps' rows in flight; lane j keeps the logit of entry j
-            ppo_f4 wk[KEEP > 0 ? KEEP : 1][4][KP];
+            // logits: entry e of every group per step; lane j keeps the logit of entry j.  Rounds of FOUR entries' broadcasts and
+            // rows in flight, then rounds of TWO for what is left: a row has ~4 affordable entries, the widest of a wave's four
+            // rows ~6, and every slot of a round costs its instructions whether a group still has an entry or not (rounds of
+            // 4 + 4: 134 us per 32 768 rows; one round of 8: 154).
             float lgj = -3.0e38f;
-            for (int c = 0; 4 * c < nmax; ++c) {
-                ppo_f4 wq[4][KP];
-                int nbe[4];
+            auto logits_round = [&](auto cs, int e0) {
+                constexpr int CS = decltype(cs)::value;
+                ppo_f4 wq[CS][KP];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int e = 4 * c + t;
-                    nbe[t] = __shfl(nbj, e < n ? e : 0, 16);
-                    nbe[t] = n > 0 ? nbe[t] : 0;
+                for (int t = 0; t < CS; ++t) {
+                    const int e = e0 + t;
+                    int nb = __shfl(nbj, e < n ? e : 0, 16);
+                    nb = n > 0 ? nb : 0;
 #pragma unroll
                     for (int m = 0; m < KP; ++m)
-                        wq[t][m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(w2 + (size_t)nbe[t] * H + pk[m]) : zero4;
+                        wq[t][m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(w2 + (size_t)nb * H + pk[m]) : zero4;
                 }
 #pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const int e = 4 * c + t;
+                for (int t = 0; t < CS; ++t) {
+                    const int e = e0 + t;
                     float d = 0.0f;
 #pragma unroll
                     for (int m = 0; m < KP; ++m) d += dot4(wq[t][m], h[m]);
                     d = row16_sum(d);
                     lgj = (j == e && e < n) ? d : lgj;
                 }
-#pragma unroll
-                for (int k = 0; k < KEEP; ++k) {
-                    if (c == k) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-#pragma unroll
-                            for (int m = 0; m < KP; ++m) wk[k][t][m] = wq[t][m];
-                    }
-                }
-            }
+            };
+            if (nmax > 0) logits_round(std::integral_constant<int, 4>{}, 0);
+            for (int e0 = 4; e0 < nmax; e0 += 2) logits_round(std::integral_constant<int, 2>{}, e0);
+            PPO_STAMP(1)
             const bool mine = j < n;
             if (mine) lgj += b2j;
             const float mx = row16_max(mine ? lgj : -3.0e38f);
@@ -329,15 +335,17 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
             if (rw.on && j == 0) loss -= fminf(s1, s2) * inv;
             const bool within = ratio >= lo && ratio <= hi;
             const float G = (rw.on && valid && (within || s1 < s2)) ? -inv * rw.adv * ratio : 0.0f;   // (a clipped sample has no gradient)
+            PPO_STAMP(2)
             const float dlj = (mine && G != 0.0f) ? G * ((hit ? icm : 0.0f) - __expf(lgj - lse)) : 0.0f;              // d loss / d logit of entry j
             if (bal(G != 0.0f) != 0ull) {
                 if (smalls && mine && G != 0.0f) lds_add(gD + nbj, dlj);
                 if (tab == 1) {
                     // ---- the W2 table: d W2[n_e] += d l_e h — no second-layer rows, no hidden-layer gradient
-                    for (int c = 0; 4 * c < nmax; ++c) {
+                    auto w2_round = [&](auto cs, int e0) {
+                        constexpr int CS = decltype(cs)::value;
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int e = 4 * c + t;
+                        for (int t = 0; t < CS; ++t) {
+                            const int e = e0 + t;
                             const int src = e < n ? e : 0;
                             const int nb = __shfl(nbj, src, 16);
                             float dl = __shfl(dlj, src, 16);
@@ -348,43 +356,37 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
                                     if (pv[m]) lds_add4(gT + (size_t)(nb - n0) * H + pk[m], dl * h[m]);
                             }
                         }
-                    }
+                    };
+                    if (nmax > 0) w2_round(std::integral_constant<int, 4>{}, 0);
+                    for (int e0 = 4; e0 < nmax; e0 += 2) w2_round(std::integral_constant<int, 2>{}, e0);
                 } else {
                     // ---- the W1t table: dh = sum_e d l_e W2[n_e], dz = dh [z > 0], d W1t[node] += dz for the observation's nodes
                     ppo_f4 dh[KP];
 #pragma unroll
                     for (int m = 0; m < KP; ++m) dh[m] = zero4;
-                    for (int c = 0; 4 * c < nmax; ++c) {
-                        ppo_f4 wq[4][KP];
-                        if (c < KEEP) {
+                    auto dh_round = [&](auto cs, int e0) {
+                        constexpr int CS = decltype(cs)::value;
+                        ppo_f4 wq[CS][KP];
 #pragma unroll
-                            for (int k = 0; k < KEEP; ++k)
-                                if (c == k) {
+                        for (int t = 0; t < CS; ++t) {
+                            const int e = e0 + t;
+                            int nb = __shfl(nbj, e < n ? e : 0, 16);
+                            nb = n > 0 ? nb : 0;
 #pragma unroll
-                                    for (int t = 0; t < 4; ++t)
-#pragma unroll
-                                        for (int m = 0; m < KP; ++m) wq[t][m] = wk[k][t][m];
-                                }
-                        } else {
-#pragma unroll
-                            for (int t = 0; t < 4; ++t) {
-                                const int e = 4 * c + t;
-                                int nb = __shfl(nbj, e < n ? e : 0, 16);
-                                nb = n > 0 ? nb : 0;
-#pragma unroll
-                                for (int m = 0; m < KP; ++m)
-                                    wq[t][m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(w2 + (size_t)nb * H + pk[m]) : zero4;
-                            }
+                            for (int m = 0; m < KP; ++m)
+                                wq[t][m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(w2 + (size_t)nb * H + pk[m]) : zero4;
                         }
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const int e = 4 * c + t;
+                        for (int t = 0; t < CS; ++t) {
+                            const int e = e0 + t;
                             float dl = __shfl(dlj, e < n ? e : 0, 16);
                             dl = e < n ? dl : 0.0f;
 #pragma unroll
                             for (int m = 0; m < KP; ++m) dh[m] += dl * wq[t][m];
                         }
-                    }
+                    };
+                    if (nmax > 0) dh_round(std::integral_constant<int, 4>{}, 0);
+                    for (int e0 = 4; e0 < nmax; e0 += 2) dh_round(std::integral_constant<int, 2>{}, e0);
                     ppo_f4 dz[KP];
 #pragma unroll
                     for (int m = 0; m < KP; ++m) {
@@ -401,6 +403,7 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
                     }
                 }
             }
+            PPO_STAMP(3)
         }
         if (own_b1) {
 #pragma unroll
@@ -493,6 +496,8 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
         tw[3 * blockIdx.x] = t_begin;
         tw[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         tw[3 * blockIdx.x + 2] = (unsigned long long)y;
+        unsigned* pw = reinterpret_cast<unsigned*>(tw + 3 * 256) + 8 * blockIdx.x;
+        for (int k = 0; k < 5; ++k) pw[k] = ph[k];
     }
 #endif
 }
@@ -612,7 +617,11 @@ static void ppo_grid(int A, int N, int H, int mb, PpoGrid& g) {
         w[y] = net == 0 ? (tab == 0 ? 0.65 : 1.0) : (net < A ? (tab == 0 ? 0.94 : 0.87) : (tab == 0 ? 0.31 : 0.21 * P));
         tot += w[y];
     }
+#ifdef SY_PPO_DIAG_BUDGET          // timing-only diagnostic: fewer blocks than CUs (is a pass slower because the chip is full?)
+    const int budget = SY_PPO_DIAG_BUDGET;
+#else
     const int budget = 256 > g.nroles ? 256 : g.nroles;                 // one 1024-thread block per CU: 256 CUs
+#endif
     const int need = (mb + 63) / 64;                                       // a 16-wave block takes 64 rows per pass
     int used = 0;
     g.first[0] = 0;
@@ -647,11 +656,11 @@ hipError_t launch_ppo_grad(PpoArgs a, float* grads, const PpoAdam& adam, hipStre
     const size_t lds = ((size_t)a.rpp * a.H + a.H + a.DN + 8) * sizeof(double) + (staged ? (size_t)a.N * a.H * sizeof(float) : 0);
     const dim3 grid(g.first[g.nroles]);
     if (a.H <= 64) {
-        if (staged) hipLaunchKernelGGL((ppo_grad_kernel<1, 0, true>), grid, dim3(1024), lds, stream, a);
-        else hipLaunchKernelGGL((ppo_grad_kernel<1, 2, false>), grid, dim3(1024), lds, stream, a);
+        if (staged) hipLaunchKernelGGL((ppo_grad_kernel<1, true>), grid, dim3(1024), lds, stream, a);
+        else hipLaunchKernelGGL((ppo_grad_kernel<1, false>), grid, dim3(1024), lds, stream, a);
     } else {
-        if (staged) hipLaunchKernelGGL((ppo_grad_kernel<2, 0, true>), grid, dim3(1024), lds, stream, a);
-        else hipLaunchKernelGGL((ppo_grad_kernel<2, 0, false>), grid, dim3(1024), lds, stream, a);
+        if (staged) hipLaunchKernelGGL((ppo_grad_kernel<2, true>), grid, dim3(1024), lds, stream, a);
+        else hipLaunchKernelGGL((ppo_grad_kernel<2, false>), grid, dim3(1024), lds, stream, a);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

@@ -167,6 +167,9 @@ __global__ __launch_bounds__(256) void ppo_pack_kernel(const PpoPackArgs p) {
     tail[i] = make_int2(__float_as_int(p.team_ret[r]), p.env_graph[r % p.B]);
 }
 
+#ifndef SY_PPO_RPG
+#define SY_PPO_RPG 1      // rows per 16-lane group and pass of the actor roles (2: two interleaved chains per group, see below)
+#endif
 #ifdef SY_PPO_DIAG_TIMES
 #define PPO_STAMP(k) { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long tn = __builtin_amdgcn_s_memtime(); ph[k] += (unsigned)(tn - tl); tl = tn; }
 #else
@@ -251,154 +254,218 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
             b1p[m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(th + 2 * NH + pk[m]) : zero4;
             gb1[m] = zero4;
         }
-        PpoRow nx = ppo_fetch_row<true>(p, im, row0, i, a, j);
-        for (; __builtin_amdgcn_readfirstlane(i - u) < p.mb; i += stride) {
+        // RPG rows per group and pass, their independent chains of lookups interleaved statement by statement.  A pass is a chain
+        // of dependent LDS / L2 round trips (broadcast -> row -> DPP sum -> ... -> LDS add) and a SIMD is ~1/3 busy at four
+        // waves, so two rows per group looked like the way to overlap two chains — measured 138 vs 133 us per 32 768 rows
+        // (-DSY_PPO_RPG=2: the per-row cost does not move; the CU's one LDS pipe, which every broadcast, staged row and
+        // float64 add goes through, is what the 16 waves queue for).  Kept as a parameter, default 1.
+        constexpr int RPG = KP == 1 ? SY_PPO_RPG : 1;          // (hidden > 64: two pieces per lane already fill the registers)
+        const int astride = stride * RPG;
+        int ia = (bx * W + wave) * 4 * RPG + u;
+        PpoRow nx[RPG];
+#pragma unroll
+        for (int s = 0; s < RPG; ++s) nx[s] = ppo_fetch_row<true>(p, im, row0, ia + 4 * s, a, j);
+        for (; __builtin_amdgcn_readfirstlane(ia - u) < p.mb; ia += astride) {
             PPO_STAMP(4)
-            const PpoRow rw = nx;
-            const int node_a = __shfl(rw.posv, a, 16);
-            // the agent's ELL row: lane j holds entry j; affordable entries compacted to lanes 0 .. n - 1 of the group
-            const uint32_t ent = p.ell[((size_t)rw.g * N + node_a) * SY_ELL_WIDTH + j];
-            // hidden vector (the W1t rows of the observation's nodes: independent loads, issued together with the ELL row)
-            ppo_f4 z[KP], h[KP];
+            PpoRow rw[RPG];
+            uint32_t ent[RPG];
+            ppo_f4 z[RPG][KP], h[RPG][KP];
 #pragma unroll
-            for (int m = 0; m < KP; ++m) z[m] = b1p[m];
+            for (int s = 0; s < RPG; ++s) {
+                rw[s] = nx[s];
+                const int node_a = __shfl(rw[s].posv, a, 16);
+                // the agent's ELL row: lane j holds entry j; affordable entries compacted to lanes 0 .. n - 1 of the group
+                ent[s] = p.ell[((size_t)rw[s].g * N + node_a) * SY_ELL_WIDTH + j];
+#pragma unroll
+                for (int m = 0; m < KP; ++m) z[s][m] = b1p[m];
+            }
+            // hidden vectors (the W1t rows of the observation's nodes: independent loads, issued together with the ELL rows)
             for (int it = 0; it < nit; ++it) {
-                const int node = __shfl(rw.posv, a == 0 ? 0 : 1 + it, 16);
 #pragma unroll
-                for (int m = 0; m < KP; ++m)
-                    if (pv[m]) z[m] += *reinterpret_cast<const ppo_f4*>(w1 + (size_t)node * H + pk[m]);
+                for (int s = 0; s < RPG; ++s) {
+                    const int node = __shfl(rw[s].posv, a == 0 ? 0 : 1 + it, 16);
+#pragma unroll
+                    for (int m = 0; m < KP; ++m)
+                        if (pv[m]) z[s][m] += *reinterpret_cast<const ppo_f4*>(w1 + (size_t)node * H + pk[m]);
+                }
             }
 #pragma unroll
-            for (int m = 0; m < KP; ++m) h[m] = relu4(z[m]);
+            for (int s = 0; s < RPG; ++s)
+#pragma unroll
+                for (int m = 0; m < KP; ++m) h[s][m] = relu4(z[s][m]);
             PPO_STAMP(0)
-            const bool legal = rw.on && (int)(ent >> 16) <= rw.bud;
-            const uint32_t L = (uint32_t)(bal(legal) >> (16 * u)) & 0xffffu;
-            const int n = __popc(L);
-            const int below = __popc(L & ((1u << j) - 1u));
-            const int dstl = legal ? below : n + (j - below);                  // a permutation of the group's lanes
-            const uint32_t cent = (uint32_t)__builtin_amdgcn_ds_permute((16 * u + dstl) << 2, (int)ent);
-            const int nbj = (int)(cent & 0xffffu);                               // lane j < n: node of affordable entry j
-            const float b2j = j < n ? b2[nbj] : 0.0f;                            // (requested now, needed after the logits)
-            // the next row's words, requested LAST: loads return in order, so a wait for anything requested after them
+            int n[RPG], nbj[RPG];
+            float b2j[RPG];
+            int nm = 0;
+#pragma unroll
+            for (int s = 0; s < RPG; ++s) {
+                const bool legal = rw[s].on && (int)(ent[s] >> 16) <= rw[s].bud;
+                const uint32_t L = (uint32_t)(bal(legal) >> (16 * u)) & 0xffffu;
+                n[s] = __popc(L);
+                const int below = __popc(L & ((1u << j) - 1u));
+                const int dstl = legal ? below : n[s] + (j - below);            // a permutation of the group's lanes
+                const uint32_t cent = (uint32_t)__builtin_amdgcn_ds_permute((16 * u + dstl) << 2, (int)ent[s]);
+                nbj[s] = (int)(cent & 0xffffu);                                  // lane j < n: node of affordable entry j
+                b2j[s] = j < n[s] ? b2[nbj[s]] : 0.0f;                           // (requested now, needed after the logits)
+                nm = max(nm, n[s]);
+            }
+            // the next rows' words, requested LAST: loads return in order, so a wait for anything requested after them
             // would wait for them too
-            nx = ppo_fetch_row<true>(p, im, row0, i + stride, a, j);
+#pragma unroll
+            for (int s = 0; s < RPG; ++s) nx[s] = ppo_fetch_row<true>(p, im, row0, ia + 4 * s + astride, a, j);
 #ifdef SY_PPO_DIAG_NOLOGIT
             const int nmax = 0;
 #else
-            const int nmax = __builtin_amdgcn_readfirstlane(max(max(__shfl(n, 0), __shfl(n, 16)), max(__shfl(n, 32), __shfl(n, 48))));
+            const int nmax = __builtin_amdgcn_readfirstlane(max(max(__shfl(nm, 0), __shfl(nm, 16)), max(__shfl(nm, 32), __shfl(nm, 48))));
 #endif
             // logits: entry e of every group per step; lane j keeps the logit of entry j.  Rounds of FOUR entries' broadcasts and
-            // rows in flight, then rounds of TWO for what is left: a row has ~4 affordable entries, the widest of a wave's four
+            // rows in flight, then rounds of TWO for what is left: a row has ~4 affordable entries, the widest of a wave's
             // rows ~6, and every slot of a round costs its instructions whether a group still has an entry or not (rounds of
             // 4 + 4: 134 us per 32 768 rows; one round of 8: 154).
-            float lgj = -3.0e38f;
+            float lgj[RPG];
+#pragma unroll
+            for (int s = 0; s < RPG; ++s) lgj[s] = -3.0e38f;
             auto logits_round = [&](auto cs, int e0) {
                 constexpr int CS = decltype(cs)::value;
-                ppo_f4 wq[CS][KP];
+                ppo_f4 wq[RPG][CS][KP];
 #pragma unroll
-                for (int t = 0; t < CS; ++t) {
-                    const int e = e0 + t;
-                    int nb = __shfl(nbj, e < n ? e : 0, 16);
-                    nb = n > 0 ? nb : 0;
+                for (int s = 0; s < RPG; ++s)
 #pragma unroll
-                    for (int m = 0; m < KP; ++m)
-                        wq[t][m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(w2 + (size_t)nb * H + pk[m]) : zero4;
-                }
+                    for (int t = 0; t < CS; ++t) {
+                        const int e = e0 + t;
+                        int nb = __shfl(nbj[s], e < n[s] ? e : 0, 16);
+                        nb = n[s] > 0 ? nb : 0;
 #pragma unroll
-                for (int t = 0; t < CS; ++t) {
-                    const int e = e0 + t;
-                    float d = 0.0f;
+                        for (int m = 0; m < KP; ++m)
+                            wq[s][t][m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(w2 + (size_t)nb * H + pk[m]) : zero4;
+                    }
 #pragma unroll
-                    for (int m = 0; m < KP; ++m) d += dot4(wq[t][m], h[m]);
-                    d = row16_sum(d);
-                    lgj = (j == e && e < n) ? d : lgj;
-                }
+                for (int s = 0; s < RPG; ++s)
+#pragma unroll
+                    for (int t = 0; t < CS; ++t) {
+                        const int e = e0 + t;
+                        float d = 0.0f;
+#pragma unroll
+                        for (int m = 0; m < KP; ++m) d += dot4(wq[s][t][m], h[s][m]);
+                        d = row16_sum(d);
+                        lgj[s] = (j == e && e < n[s]) ? d : lgj[s];
+                    }
             };
             if (nmax > 0) logits_round(std::integral_constant<int, 4>{}, 0);
             for (int e0 = 4; e0 < nmax; e0 += 2) logits_round(std::integral_constant<int, 2>{}, e0);
             PPO_STAMP(1)
-            const bool mine = j < n;
-            if (mine) lgj += b2j;
-            const float mx = row16_max(mine ? lgj : -3.0e38f);
-            const float ex = mine ? __expf(lgj - mx) : 0.0f;
-            const float se = row16_sum(ex);
-            const bool hit = mine && nbj == rw.act;
-            const float cm = row16_sum(hit ? 1.0f : 0.0f);
-            const float la = row16_sum(hit ? lgj : 0.0f);
-            // clipped surrogate (mappo_agent.py:284-291) and its derivative with respect to the new log-probability
-            const bool valid = rw.act >= 0 && cm > 0.0f;          // an agent without a legal action: ratio 1, no gradient
-            const float lse = valid ? mx + __logf(se) : 0.0f;
-            const float icm = valid ? 1.0f / cm : 0.0f;
-            const float new_lp = valid ? la * icm - lse : 0.0f;
-            const float ratio = __expf(new_lp - (valid ? rw.olp : 0.0f));
-            const float s1 = ratio * rw.adv, s2 = fminf(fmaxf(ratio, lo), hi) * rw.adv;
-            if (rw.on && j == 0) loss -= fminf(s1, s2) * inv;
-            const bool within = ratio >= lo && ratio <= hi;
-            const float G = (rw.on && valid && (within || s1 < s2)) ? -inv * rw.adv * ratio : 0.0f;   // (a clipped sample has no gradient)
+            bool mine[RPG];
+            float G[RPG], dlj[RPG];
+#pragma unroll
+            for (int s = 0; s < RPG; ++s) {
+                mine[s] = j < n[s];
+                if (mine[s]) lgj[s] += b2j[s];
+                const float mx = row16_max(mine[s] ? lgj[s] : -3.0e38f);
+                const float ex = mine[s] ? __expf(lgj[s] - mx) : 0.0f;
+                const float se = row16_sum(ex);
+                const bool hit = mine[s] && nbj[s] == rw[s].act;
+                const float cm = row16_sum(hit ? 1.0f : 0.0f);
+                const float la = row16_sum(hit ? lgj[s] : 0.0f);
+                // clipped surrogate (mappo_agent.py:284-291) and its derivative with respect to the new log-probability
+                const bool valid = rw[s].act >= 0 && cm > 0.0f;       // an agent without a legal action: ratio 1, no gradient
+                const float lse = valid ? mx + __logf(se) : 0.0f;
+                const float icm = valid ? 1.0f / cm : 0.0f;
+                const float new_lp = valid ? la * icm - lse : 0.0f;
+                const float ratio = __expf(new_lp - (valid ? rw[s].olp : 0.0f));
+                const float s1 = ratio * rw[s].adv, s2 = fminf(fmaxf(ratio, lo), hi) * rw[s].adv;
+                if (rw[s].on && j == 0) loss -= fminf(s1, s2) * inv;
+                const bool within = ratio >= lo && ratio <= hi;
+                G[s] = (rw[s].on && valid && (within || s1 < s2)) ? -inv * rw[s].adv * ratio : 0.0f;   // (a clipped sample has no gradient)
+                dlj[s] = (mine[s] && G[s] != 0.0f) ? G[s] * ((hit ? icm : 0.0f) - __expf(lgj[s] - lse)) : 0.0f;   // d loss / d logit of entry j
+            }
             PPO_STAMP(2)
-            const float dlj = (mine && G != 0.0f) ? G * ((hit ? icm : 0.0f) - __expf(lgj - lse)) : 0.0f;              // d loss / d logit of entry j
-            if (bal(G != 0.0f) != 0ull) {
-                if (smalls && mine && G != 0.0f) lds_add(gD + nbj, dlj);
+            bool anyg = false;
+#pragma unroll
+            for (int s = 0; s < RPG; ++s) anyg = anyg | (G[s] != 0.0f);
+            if (bal(anyg) != 0ull) {
+#pragma unroll
+                for (int s = 0; s < RPG; ++s)
+                    if (smalls && mine[s] && G[s] != 0.0f) lds_add(gD + nbj[s], dlj[s]);
                 if (tab == 1) {
                     // ---- the W2 table: d W2[n_e] += d l_e h — no second-layer rows, no hidden-layer gradient
                     auto w2_round = [&](auto cs, int e0) {
                         constexpr int CS = decltype(cs)::value;
+                        int nbs[RPG][CS];
+                        float dls[RPG][CS];
 #pragma unroll
-                        for (int t = 0; t < CS; ++t) {
-                            const int e = e0 + t;
-                            const int src = e < n ? e : 0;
-                            const int nb = __shfl(nbj, src, 16);
-                            float dl = __shfl(dlj, src, 16);
-                            dl = e < n ? dl : 0.0f;
-                            if (dl != 0.0f && nb >= n0 && nb < n1) {
+                        for (int s = 0; s < RPG; ++s)
 #pragma unroll
-                                for (int m = 0; m < KP; ++m)
-                                    if (pv[m]) lds_add4(gT + (size_t)(nb - n0) * H + pk[m], dl * h[m]);
+                            for (int t = 0; t < CS; ++t) {
+                                const int e = e0 + t;
+                                const int src = e < n[s] ? e : 0;
+                                nbs[s][t] = __shfl(nbj[s], src, 16);
+                                const float dl = __shfl(dlj[s], src, 16);
+                                dls[s][t] = e < n[s] ? dl : 0.0f;
                             }
-                        }
+#pragma unroll
+                        for (int s = 0; s < RPG; ++s)
+#pragma unroll
+                            for (int t = 0; t < CS; ++t) {
+                                if (dls[s][t] != 0.0f && nbs[s][t] >= n0 && nbs[s][t] < n1) {
+#pragma unroll
+                                    for (int m = 0; m < KP; ++m)
+                                        if (pv[m]) lds_add4(gT + (size_t)(nbs[s][t] - n0) * H + pk[m], dls[s][t] * h[s][m]);
+                                }
+                            }
                     };
                     if (nmax > 0) w2_round(std::integral_constant<int, 4>{}, 0);
                     for (int e0 = 4; e0 < nmax; e0 += 2) w2_round(std::integral_constant<int, 2>{}, e0);
                 } else {
                     // ---- the W1t table: dh = sum_e d l_e W2[n_e], dz = dh [z > 0], d W1t[node] += dz for the observation's nodes
-                    ppo_f4 dh[KP];
+                    ppo_f4 dh[RPG][KP];
 #pragma unroll
-                    for (int m = 0; m < KP; ++m) dh[m] = zero4;
+                    for (int s = 0; s < RPG; ++s)
+#pragma unroll
+                        for (int m = 0; m < KP; ++m) dh[s][m] = zero4;
                     auto dh_round = [&](auto cs, int e0) {
                         constexpr int CS = decltype(cs)::value;
-                        ppo_f4 wq[CS][KP];
+                        ppo_f4 wq[RPG][CS][KP];
+                        float dls[RPG][CS];
 #pragma unroll
-                        for (int t = 0; t < CS; ++t) {
-                            const int e = e0 + t;
-                            int nb = __shfl(nbj, e < n ? e : 0, 16);
-                            nb = n > 0 ? nb : 0;
+                        for (int s = 0; s < RPG; ++s)
 #pragma unroll
-                            for (int m = 0; m < KP; ++m)
-                                wq[t][m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(w2 + (size_t)nb * H + pk[m]) : zero4;
-                        }
+                            for (int t = 0; t < CS; ++t) {
+                                const int e = e0 + t;
+                                const int src = e < n[s] ? e : 0;
+                                int nb = __shfl(nbj[s], src, 16);
+                                nb = n[s] > 0 ? nb : 0;
+                                const float dl = __shfl(dlj[s], src, 16);
+                                dls[s][t] = e < n[s] ? dl : 0.0f;
 #pragma unroll
-                        for (int t = 0; t < CS; ++t) {
-                            const int e = e0 + t;
-                            float dl = __shfl(dlj, e < n ? e : 0, 16);
-                            dl = e < n ? dl : 0.0f;
+                                for (int m = 0; m < KP; ++m)
+                                    wq[s][t][m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(w2 + (size_t)nb * H + pk[m]) : zero4;
+                            }
 #pragma unroll
-                            for (int m = 0; m < KP; ++m) dh[m] += dl * wq[t][m];
-                        }
+                        for (int s = 0; s < RPG; ++s)
+#pragma unroll
+                            for (int t = 0; t < CS; ++t)
+#pragma unroll
+                                for (int m = 0; m < KP; ++m) dh[s][m] += dls[s][t] * wq[s][t][m];
                     };
                     if (nmax > 0) dh_round(std::integral_constant<int, 4>{}, 0);
                     for (int e0 = 4; e0 < nmax; e0 += 2) dh_round(std::integral_constant<int, 2>{}, e0);
-                    ppo_f4 dz[KP];
+                    ppo_f4 dz[RPG][KP];
 #pragma unroll
-                    for (int m = 0; m < KP; ++m) {
-                        dz[m] = gate4(z[m], dh[m]);
-                        gb1[m] += dz[m];
-                    }
+                    for (int s = 0; s < RPG; ++s)
+#pragma unroll
+                        for (int m = 0; m < KP; ++m) {
+                            dz[s][m] = gate4(z[s][m], dh[s][m]);
+                            gb1[m] += dz[s][m];
+                        }
                     for (int it = 0; it < nit; ++it) {
-                        const int node = __shfl(rw.posv, a == 0 ? 0 : 1 + it, 16);
-                        if (G != 0.0f && node >= n0 && node < n1) {
 #pragma unroll
-                            for (int m = 0; m < KP; ++m)
-                                if (pv[m]) lds_add4(gT + (size_t)(node - n0) * H + pk[m], dz[m]);
+                        for (int s = 0; s < RPG; ++s) {
+                            const int node = __shfl(rw[s].posv, a == 0 ? 0 : 1 + it, 16);
+                            if (G[s] != 0.0f && node >= n0 && node < n1) {
+#pragma unroll
+                                for (int m = 0; m < KP; ++m)
+                                    if (pv[m]) lds_add4(gT + (size_t)(node - n0) * H + pk[m], dz[s][m]);
+                            }
                         }
                     }
                 }
@@ -622,7 +689,7 @@ static void ppo_grid(int A, int N, int H, int mb, PpoGrid& g) {
 #else
     const int budget = 256 > g.nroles ? 256 : g.nroles;                 // one 1024-thread block per CU: 256 CUs
 #endif
-    const int need = (mb + 63) / 64;                                       // a 16-wave block takes 64 rows per pass
+    const int need = (mb + 64 * SY_PPO_RPG - 1) / (64 * SY_PPO_RPG);       // a 16-wave block takes 64 (x rows per group) rows per pass
     int used = 0;
     g.first[0] = 0;
     for (int y = 0; y < g.nroles; ++y) {

@@ -297,6 +297,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the separately timed trajectory all-gather")
     ap.add_argument("--step-api", action="store_true", help="also time the per-step sy_env_step launch path")
     ap.add_argument("--no-config3", action="store_true", help="skip the configs[2] sub-record (learned policy + update)")
+    ap.add_argument("--no-belief-layout", action="store_true", help="diagnostic: belief scratch in node order (no bank-aware layout)")
     ap.add_argument("--config3-graph", action="store_true", help="configs[2] sub-record: replay every minibatch step as one HIP graph "
                     "(no gain on the fused update: a minibatch is two launches)")
     args = ap.parse_args()
@@ -331,7 +332,7 @@ def main():
     weights = np.full(11, 0.5)
     env = sy.BatchedScotlandYardEnv(B, boards, P, args.money, weights, seed=args.seed, reveal_interval=args.reveal,
                                     env_id_offset=rank * B, waves_per_block=args.wpb, device=device,
-                                    with_belief=not args.no_belief)
+                                    with_belief=not args.no_belief, belief_layout=not args.no_belief_layout)
     out = None if args.no_record else env.alloc_rollout(T, record_mask=not args.no_mask_record)
     full = not (args.no_record or args.no_belief or args.no_mask_record)
     do_verify = full and not args.no_verify and rank == 0

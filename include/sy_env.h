@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define SY_ABI_VERSION 6
+#define SY_ABI_VERSION 7
 #define SY_ELL_WIDTH 16
 #define SY_MAX_AGENTS 8
 #define SY_MAX_NODES 1024
@@ -147,6 +147,14 @@ int sy_env_rollout_kernel_name(const sy_env *env, int32_t record, char *buf, int
  * boards of 129..256 nodes; wider pools, and 0 = unknown, take the general paired scan — same results, slower) */
 int sy_env_set_graph_pool(sy_env *env, const uint32_t *ell, const uint16_t *apsp, const float *inv_deg,
                           const int32_t *env_graph, int32_t max_degree /* widest ELL row of the pool; 0 = unknown */);
+/* optional, boards of up to 256 nodes: the LDS layout of the fused rollout's belief filter (ParticleBeliefTracker.update's
+ * diffusion step, belief_module.py:69-111) — gather_offsets uint16 [G][N][16]: for every node the scratch BYTE offsets
+ * (entry * 8; padding = N * 8, the zero entry) of its neighbours in the order they are visited, a permutation of the node's
+ * ELL row; node_slot uint16 [G][node_stride]: the entry a node's own value goes to (< node_stride + 16, never N).  Chosen
+ * per board (student_mechanism_design_amd/graph.py::belief_layout) so that the 32 addresses a half-wave gathers per
+ * instruction fall on 32 different LDS bank pairs; NULL, NULL = entry u for node u, ELL order.  Results are the same filter
+ * (the sum over a node's neighbours in another order: float32 rounding). */
+int sy_env_set_belief_layout(sy_env *env, const uint16_t *gather_offsets, const uint16_t *node_slot);
 /* the 11 reward weights (host array, order = REWARD_WEIGHT_NAMES reward_net.py:5-17) and the device
  * tables exp_tab[d] = exp(-d), cov_tab[v] = exp(-log1p(v)) (reward_calculator.py:184-207) */
 int sy_env_set_rewards(sy_env *env, const double *weights_host, const double *exp_tab, int32_t n_exp,

@@ -11,7 +11,7 @@ MAX_AGENTS = 8
 MAX_NODES = 1024
 NUM_WEIGHTS = 11
 MRX_MONEY = 1000
-ABI_VERSION = 6
+ABI_VERSION = 7
 STATUS_BELIEF_WAIT_EXPIRED = 1
 STATUS_RING_WAIT_EXPIRED = 2
 
@@ -75,7 +75,7 @@ EXPORTS = ["sy_abi_version", "sy_record_words", "sy_last_error", "sy_env_create"
            "sy_masked_categorical_sample", "sy_mappo_policy_act", "sy_env_bind_status", "sy_env_status",
            "sy_returns_advantages", "sy_build_id", "sy_env_rollout_kernel_name",
            "sy_gnn_padded_features", "sy_gnn_param_floats", "sy_gnn_q_act",
-           "sy_ppo_slab_floats", "sy_ppo_scratch_floats", "sy_mappo_ppo_grad", "sy_ppo_image_bytes", "sy_ppo_pack", "sy_ppo_adam_step"]
+           "sy_ppo_slab_floats", "sy_ppo_scratch_floats", "sy_mappo_ppo_grad", "sy_ppo_image_bytes", "sy_ppo_pack", "sy_ppo_adam_step", "sy_env_set_belief_layout"]
 
 _lib = None
 
@@ -104,6 +104,7 @@ def load():
     lib.sy_env_destroy.argtypes = [vp]
     lib.sy_env_launch_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     lib.sy_env_set_graph_pool.argtypes = [vp, vp, vp, vp, vp, i32]
+    lib.sy_env_set_belief_layout.argtypes = [vp, vp, vp]
     lib.sy_env_set_rewards.argtypes = [vp, C.POINTER(C.c_double), vp, i32, vp, i32]
     lib.sy_env_bind_state.argtypes = [vp, C.POINTER(EnvState)]
     lib.sy_env_set_policy.argtypes = [vp, C.POINTER(MappoWeights), i32]

@@ -156,6 +156,16 @@ int sy_env_set_graph_pool(sy_env* env, const uint32_t* ell, const uint16_t* apsp
     return SY_OK;
 }
 
+int sy_env_set_belief_layout(sy_env* env, const uint16_t* gather_offsets, const uint16_t* node_slot) {
+    if (!env) return fail(SY_ERR_INVALID, "sy_env_set_belief_layout: null env%s");
+    if ((gather_offsets == nullptr) != (node_slot == nullptr)) return fail(SY_ERR_INVALID, "sy_env_set_belief_layout: both tables or neither%s");
+    if (gather_offsets && (reinterpret_cast<uintptr_t>(gather_offsets) & 7)) return fail(SY_ERR_INVALID, "sy_env_set_belief_layout: gather_offsets must be 8-byte aligned%s");
+    if (gather_offsets && env->p.N > 256) return fail(SY_ERR_INVALID, "sy_env_set_belief_layout: boards of more than 256 nodes run on kernels without a layout%s");
+    env->p.bel_gather = gather_offsets;
+    env->p.bel_slot = node_slot;
+    return SY_OK;
+}
+
 int sy_env_set_rewards(sy_env* env, const double* w, const double* exp_tab, int32_t n_exp, const double* cov_tab,
                        int32_t n_cov) {
     if (!env || !w || !exp_tab || !cov_tab) return fail(SY_ERR_INVALID, "sy_env_set_rewards: null argument%s");

@@ -782,16 +782,20 @@ __device__ __forceinline__ void load_coeffs(const EngineParams& p, int lane, dou
 
 // Stage the block's board: ELL rows (coalesced 16-byte loads), the belief gather offsets derived
 // from them, and (TABLES) the reward lookup tables.
-template <bool TABLES, int CSHIFT = 2>
+// LAYOUT: the kernel's belief filter honours the host's bank-aware scratch layout (sy_env_set_belief_layout): the gather
+// offsets then come from the pool's table instead of the ELL order.
+template <bool TABLES, int CSHIFT = 2, bool LAYOUT = false>
 __device__ __forceinline__ void stage_block(const EngineParams& p, const LdsMap& L, int g, int N) {
     const uint4* src = reinterpret_cast<const uint4*>(p.ell + (size_t)g * N * kD);
     uint4* dst = reinterpret_cast<uint4*>(L.ell_s);
+    const uint2* lay = (LAYOUT && p.bel_gather) ? reinterpret_cast<const uint2*>(p.bel_gather + (size_t)g * N * kD) : nullptr;
     for (int i = threadIdx.x; i < N * 4; i += blockDim.x) {
         const uint4 v = src[i];
         dst[i] = v;
         uint2 o;   // byte offsets of the neighbours' belief-scratch entries (4 B each, 8 B in the paired kernel)
         o.x = ((v.x & 0xffffu) << CSHIFT) | ((v.y & 0xffffu) << (16 + CSHIFT));
         o.y = ((v.z & 0xffffu) << CSHIFT) | ((v.w & 0xffffu) << (16 + CSHIFT));
+        if (LAYOUT && lay) o = lay[i];
         reinterpret_cast<uint2*>(L.boff_s)[i] = o;
     }
     if (TABLES) {

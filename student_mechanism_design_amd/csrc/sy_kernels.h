@@ -27,6 +27,8 @@ struct EngineParams {
     const uint32_t* ell;          // [G][N][16]
     const uint16_t* apsp;         // [G][N][N]
     const float* inv_deg;         // [G][NS]
+    const uint16_t* bel_gather;   // [G][N][16] scratch byte offsets of every node's neighbour visits (sy_env_set_belief_layout) or nullptr
+    const uint16_t* bel_slot;     // [G][NS]    scratch entry of every node's own value, or nullptr: entry = node
     const int32_t* env_graph;     // [B]
     double w[SY_NUM_WEIGHTS];
     const double* exp_tab;

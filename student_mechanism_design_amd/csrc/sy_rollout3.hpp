@@ -795,7 +795,8 @@ struct BeliefLanes {
     uint32_t ga[NR][8];                                    // LDS addresses of the first eight neighbour entries
     int slab_w[NR];
     uint64_t in_m[NR];                                     // lanes whose node k exists
-    uint32_t c_off, c_mine, off_bel;
+    uint32_t c_off, off_bel;
+    uint32_t cw[NR];                                       // LDS address of my nodes' own scratch entries
     int j0;
     bool mine;
 
@@ -804,7 +805,7 @@ struct BeliefLanes {
         c_off = lds_off(E.c_s);
         j0 = NR * lane;
         mine = j0 < NS;
-        c_mine = c_off + (uint32_t)j0 * 8u;
+        const uint16_t* const slot_of = p.bel_gather ? p.bel_slot + (size_t)g * NS : nullptr;   // (the layout's two tables go together)
         off_bel = ((uint32_t)e * (uint32_t)NS + (uint32_t)j0) * 4u;
         const float* r0 = p.st.belief + (size_t)e * NS + j0;
         const float* r1 = r0 + NS;
@@ -816,6 +817,7 @@ struct BeliefLanes {
             b[k].y = (mine && live1 && j < N) ? r1[k] : 0.0f;
             ideg[k] = (mine && j < N) ? dg[k] : 0.0f;
             const int jr = j < N ? j : N - 1;
+            cw[k] = c_off + 8u * (uint32_t)(j < N ? ((slot_of && mine) ? (int)slot_of[j] : j) : N);   // (lanes past the board write their 0 to the zero entry)
             const uint4 o = *reinterpret_cast<const uint4*>(L.boff_s + (jr << 4));
             ga[k][0] = c_off + (o.x & 0xffffu); ga[k][1] = c_off + (o.x >> 16);
             ga[k][2] = c_off + (o.y & 0xffffu); ga[k][3] = c_off + (o.y >> 16);
@@ -830,7 +832,7 @@ struct BeliefLanes {
             if (!inr || deg == 0) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) ga[k][q] = zero_e;
-                if (inr) { ga[k][0] = c_off + (uint32_t)j * 8u; ideg[k] = 1.0f; }
+                if (inr) { ga[k][0] = cw[k]; ideg[k] = 1.0f; }
             }
             int need = (deg + 3) >> 2;
 #pragma unroll
@@ -859,17 +861,10 @@ struct BeliefLanes {
                                          bool norm_now) {
         if (bf0 == 0 || bf1 == 0) {
             SY_HOT(h_belstep);
-            if (mine) {      // c = b / deg of my nodes: NR * 8 contiguous bytes of the interleaved scratch
-                if (NR == 1) {
-                    *lds_at<v2f>(c_mine) = b[0] * ideg[0];
-                } else {
-                    typedef float v4f __attribute__((ext_vector_type(4)));
+            if (mine) {      // c = b / deg of my nodes, each to its own entry of the interleaved scratch (node order, or the
+                             // pool's bank-aware layout: the 16 lanes of an LDS store cycle then hit 16 different bank pairs)
 #pragma unroll
-                    for (int k = 0; k + 1 < NR; k += 2) {
-                        const v2f c0 = b[k] * ideg[k], c1 = b[k + 1] * ideg[k + 1];
-                        *lds_at<v4f>(c_mine + (uint32_t)k * 8u) = (v4f){c0.x, c0.y, c1.x, c1.y};
-                    }
-                }
+                for (int k = 0; k < NR; ++k) *lds_at<v2f>(cw[k]) = b[k] * ideg[k];
             }
             wave_lds_fence();
             constexpr int GR = NR < 2 ? NR : 2;
@@ -1192,7 +1187,7 @@ __global__ __launch_bounds__(1024, 4) void rollout3_kernel(const EngineParams p,
     const EnvLds E = env_lds(L.env_base, slot, p.wave_lds_bytes, A, NS);
     int g = __builtin_amdgcn_readfirstlane(p.env_graph[e0 < B ? e0 : B - 1]);
     g = g < 0 ? 0 : (g >= p.G ? p.G - 1 : g);
-    stage_block<true, 3>(p, L, g, N);
+    stage_block<true, 3, true>(p, L, g, N);
     const EnvLds E1 = env_lds(L.env_base, slot + 1, p.wave_lds_bytes, A, NS);
     if (!helper_role && lane == 0) {
         E.sync[0] = 0; E.sync[1] = 0;

@@ -13,7 +13,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from .graph import Board, DevicePool, PackedPool, pack_pool, reward_tables
+from .graph import Board, DevicePool, PackedPool, belief_lanes, pack_pool, reward_tables
+from .graph import belief_layout as belief_layout_of
 
 # order of REWARD_WEIGHT_NAMES, src/reward_net.py:5-17
 REWARD_WEIGHT_NAMES = [
@@ -122,7 +123,7 @@ class BatchedScotlandYardEnv:
                  agent_money: int, reward_weights, max_timestep: int = 250, reveal_interval: int = 0,
                  police_evidence: bool = False, belief_init_onehot: bool = False, auto_reset: bool = True,
                  with_belief: bool = True, env_graph=None, env_id_offset: int = 0, waves_per_block: int = 0,
-                 device: Union[str, torch.device] = "cuda", seed: int = 0):
+                 device: Union[str, torch.device] = "cuda", seed: int = 0, belief_layout: bool = True):
         self.lib = _lib.load()  # raises if the HIP library is missing
         if not torch.cuda.is_available():
             raise _lib.EngineError("BatchedScotlandYardEnv needs a GPU (torch.cuda.is_available() is False); "
@@ -181,6 +182,16 @@ class BatchedScotlandYardEnv:
         self.max_degree = int(((self.pool.ell & 0xFFFF) < self.N).sum(axis=2).max())
         _lib.check(self.lib.sy_env_set_graph_pool(self._handle, _ptr(self.ell), _ptr(self.apsp), _ptr(self.inv_deg),
                                                   _ptr(self.env_graph), self.max_degree), "sy_env_set_graph_pool")
+        # ---- the belief filter's bank-aware LDS layout (graph.belief_layout: per board, which scratch entry a node's value goes
+        # to and in which order a node visits its neighbours, so that a half-wave's gathers hit 32 different bank pairs)
+        self.belief_gather = self.belief_slot = None
+        if with_belief and belief_layout and belief_lanes(self.N) > 0:
+            lay = [belief_layout_of(self.pool.ell[g], self.N, self.NS) for g in range(self.G)]
+            if all(x is not None for x in lay):
+                self.belief_slot = torch.from_numpy(np.stack([x[0] for x in lay]).view(np.int16).copy()).to(dev)
+                self.belief_gather = torch.from_numpy(np.stack([x[1] for x in lay]).view(np.int16).copy()).to(dev)
+                _lib.check(self.lib.sy_env_set_belief_layout(self._handle, _ptr(self.belief_gather), _ptr(self.belief_slot)),
+                           "sy_env_set_belief_layout")
         # ---- reward weights + tables
         exp_tab, cov_tab = reward_tables()
         self.exp_tab = torch.from_numpy(exp_tab).to(dev)

@@ -384,3 +384,168 @@ def gcn_tables(boards: Sequence[Board], directed: bool = True):
             coef[g, v, fill[v]] = np.float32(dinv[u] * dinv[v])
             fill[v] += 1
     return nbr, coef, self_coef
+
+
+# ---- the belief filter's LDS layout: which scratch slot a node's c = b / deg goes to, and in which order a node gathers its
+# neighbours, chosen per board so that the gathers of a wave hit distinct LDS banks ------------------------------------------
+def belief_lanes(num_nodes: int) -> int:
+    """Nodes per lane of the pipeline kernel's belief filter (csrc/sy_rollout3.hpp::BeliefLanes): lane L owns nodes
+    NR * L ... NR * L + NR - 1; boards of more than 256 nodes run on the older kernels (no layout)."""
+    return 1 if num_nodes <= 64 else (2 if num_nodes <= 128 else (4 if num_nodes <= 256 else 0))
+
+
+def _edge_colour(edges, num_left, num_right, K):
+    """Proper K-edge-colouring of a bipartite multigraph (edges = [(x, y)], x < num_left, y < num_right) by alternating
+    paths (König): colour[e] in [0, K) with no two edges at one vertex sharing a colour, wherever both endpoints have at
+    most K edges; an edge at an over-full right vertex gets a colour free at its left vertex only (a conflict remains)."""
+    at_l = -np.ones((num_left, K), dtype=np.int64)       # edge holding colour k at left vertex x
+    at_r = -np.ones((num_right, K), dtype=np.int64)
+    colour = -np.ones(len(edges), dtype=np.int64)
+    for e, (x, y) in enumerate(edges):
+        free_l = np.flatnonzero(at_l[x] < 0)
+        free_r = np.flatnonzero(at_r[y] < 0)
+        if free_l.size == 0:
+            raise ValueError("a left vertex has more than K edges")
+        a = int(free_l[0])
+        if free_r.size == 0:                             # over-full right vertex: the conflict stays
+            colour[e] = a
+            at_l[x, a] = e
+            continue
+        both = np.intersect1d(free_l, free_r)
+        if both.size:
+            a = int(both[0])
+        else:
+            b = int(free_r[0])
+            # free colour a at y: flip a <-> b along the alternating path that starts at y with its a-edge (it cannot
+            # reach x: x has no a-edge, and the path enters left vertices by a-edges only)
+            path, side, v, want = [], 1, y, a
+            while True:
+                f = at_r[v, want] if side == 1 else at_l[v, want]
+                if f < 0:
+                    break
+                path.append(int(f))
+                v = edges[f][0] if side == 1 else edges[f][1]
+                side ^= 1
+                want = b if want == a else a
+            for f in path:
+                fx, fy = edges[f]
+                at_l[fx, colour[f]] = -1
+                at_r[fy, colour[f]] = -1
+            for f in path:
+                fx, fy = edges[f]
+                colour[f] = b if colour[f] == a else a
+                at_l[fx, colour[f]] = f
+                at_r[fy, colour[f]] = f
+        colour[e] = a
+        at_l[x, a] = e
+        at_r[y, a] = e
+    return colour
+
+
+def belief_layout(ell_rows: np.ndarray, num_nodes: int, node_stride: int):
+    """(slot uint16 [NS], gather uint16 [N][16]) for one board, or None for boards the pipeline kernel does not run.
+
+    The filter's diffusion step gathers, for every node, c[u] = b[u] / deg(u) of its neighbours u from an LDS scratch of 8-byte
+    entries (both episodes of a pair): 8 gathers per node (8 more only on boards with a node of more than 8 neighbours),
+    each a wave-wide `ds_read_b64` of 64 scattered addresses.  LDS banking is per half-wave (MI355X: 64 banks of 4 bytes, an
+    8-byte entry takes a pair: entry s sits on pair s mod 32); in node order the 32 addresses of a half-wave land ~3.5-deep
+    on the fullest pair: the filter was the engine's bank-conflict source (48.9 of its 154 LDS cycles per env-step).
+    Both the entry a node's value goes to and the ORDER in which a node visits its neighbours are free, so:
+      1. nodes get one of 32 colours (bank pairs), greedily, largest in-degree first, such that no colour is asked for more
+         than 8 times by the nodes of one (lane part, half-wave) group — the 8 gather instructions of that group;
+      2. per group, the bipartite multigraph (node -> colours of its neighbours) is edge-coloured with 8 colours (König):
+         the colour of an edge is the gather instruction in which that neighbour is visited, so no instruction of a
+         half-wave asks one bank pair for two different entries;
+      3. entries: colour g owns slots g, g + 32, ...; slot N stays the zero entry that padding gathers read.
+    `gather[v][k]` is the scratch BYTE offset of node v's k-th visit (slot * 8; padding -> N * 8)."""
+    N, NS = int(num_nodes), int(node_stride)
+    NR = belief_lanes(N)
+    if NR == 0:
+        return None
+    rows = np.asarray(ell_rows, dtype=np.uint32).reshape(N, 16)
+    nbr = (rows & 0xFFFF).astype(np.int64)
+    nslots = NS + 16
+    zero = N
+    K, C = 8, 32
+    neigh = [[int(u) for u in nbr[v] if u < N] for v in range(N)]
+    if max((len(x) for x in neigh), default=0) > 16:
+        return None
+    group = lambda v: (v % NR) * 2 + ((v // NR) >> 5)            # noqa: E731   (lane part r, half-wave) of node v's lane
+    ngroups = 2 * NR
+    first = [x[:K] for x in neigh]                                # visits 0..7; the rest (rare) in visits 8..15
+    second = [x[K:] for x in neigh]
+    # 1. colours
+    cap = np.array([sum(1 for s in range(c, nslots, C) if s != zero) for c in range(C)])
+    want = np.zeros((N, ngroups), dtype=np.int64)                 # how often group g asks for node u (first visits)
+    for v in range(N):
+        for u in first[v]:
+            want[u, group(v)] += 1
+    cap[zero % C] = 0                                             # nobody shares the zero entry's bank pair
+    load = np.zeros((ngroups, C), dtype=np.int64)
+    used = np.zeros(C, dtype=np.int64)
+    colour = -np.ones(N, dtype=np.int64)
+    # the lanes' own entries are written by `ds_write_b64` (16 contiguous lanes per LDS cycle, 32 banks: entry mod 16): the 16
+    # nodes of one (lane part, quarter-wave) take 16 different residues mod 16
+    wgroup = lambda v: (v % NR) * 4 + ((v // NR) >> 4)           # noqa: E731
+    taken = np.zeros((4 * NR, 16), dtype=bool)
+    for u in np.argsort(-want.sum(1), kind="stable"):
+        peak = (load + want[u][:, None]).max(0).astype(np.float64)   # fullest group-colour cell if u took colour c
+        peak[used >= cap] = np.inf
+        peak[np.tile(taken[wgroup(u)], 2)] = np.inf
+        if not np.isfinite(peak).any():                           # (cannot happen while 16 residues x 2 >= the group's nodes)
+            peak = (load + want[u][:, None]).max(0).astype(np.float64)
+            peak[used >= cap] = np.inf
+        best = np.flatnonzero(peak == peak.min())
+        c = int(best[np.argmin(used[best])])
+        colour[u] = c
+        used[c] += 1
+        taken[wgroup(u), c % 16] = True
+        load[:, c] += want[u]
+    # 3. slots
+    slot = np.zeros(NS, dtype=np.uint16)
+    nxt = {c: [s for s in range(c, nslots, C) if s != zero] for c in range(C)}
+    for u in range(N):
+        slot[u] = nxt[int(colour[u])].pop(0)
+    for u in range(N, NS):
+        slot[u] = zero
+    # 2. visit order per group
+    gather = np.full((N, 16), zero * 8, dtype=np.uint16)
+    for which, base in ((first, 0), (second, K)):
+        for g in range(ngroups):
+            members = [v for v in range(N) if group(v) == g and which[v]]
+            if not members:
+                continue
+            index = {v: i for i, v in enumerate(members)}
+            edges = [(index[v], int(colour[u])) for v in members for u in which[v]]
+            who = [u for v in members for u in which[v]]
+            col = _edge_colour(edges, len(members), C, K)
+            for (x, _), u, k in zip(edges, who, col):
+                gather[members[x], base + int(k)] = int(slot[u]) * 8
+    return slot, gather
+
+
+def belief_bank_conflicts(gather: np.ndarray, slot: np.ndarray, num_nodes: int, node_stride: int) -> dict:
+    """Extra LDS cycles of one diffusion step under the MI355X bank model (a `ds_read_b64` is served per half-wave, bank pair
+    = entry mod 32, identical addresses broadcast, every further distinct entry on a busy pair costs a cycle): the 8 (or 16)
+    gathers of every lane part, and the scatter of the lanes' own entries."""
+    N, NR = int(num_nodes), belief_lanes(num_nodes)
+    zero = N * 8
+    wide = bool((gather[:, 8:] != zero).any())
+    extra_g = extra_w = 0
+    for r in range(NR):
+        for half in range(2):
+            lanes = range(32 * half, 32 * half + 32)
+            for k in range(16 if wide else 8):
+                addr = {int(gather[NR * L + r, k]) if NR * L + r < N else zero for L in lanes}
+                pairs = {}
+                for a in addr:
+                    pairs[(a // 8) % 32] = pairs.get((a // 8) % 32, 0) + 1
+                extra_g += sum(c - 1 for c in pairs.values())
+        # the lanes' own entries: ds_write_b64, 4 x 16 contiguous lanes, bank pair of the 32-bank store view = entry mod 16
+        for q in range(4):
+            own = {int(slot[NR * L + r]) for L in range(16 * q, 16 * q + 16) if NR * L + r < N}
+            pairs = {}
+            for s in own:
+                pairs[s % 16] = pairs.get(s % 16, 0) + 1
+            extra_w += sum(c - 1 for c in pairs.values())
+    return {"gather_extra_cycles": extra_g, "store_extra_cycles": extra_w, "gather_instructions": NR * (16 if wide else 8)}

@@ -787,7 +787,8 @@ __device__ __forceinline__ void move_wave3(const EngineParams& p, const LdsMap& 
 // Normalisation: without evidence the diffusion conserves the mass (every node of a connected board has
 // neighbours), so the filter renormalises only every 8th step and when it leaves; with police evidence (mass is
 // removed, possibly all of it -> uniform fallback) every step, as the reference filter does.
-template <int NR>
+template <int NR, bool LAY>      // LAY: honour the pool's bank-aware scratch layout (the random-policy instances; the policy
+                                 // instances, whose helper sits on the VGPR limit and is not LDS-bound, keep node order)
 struct BeliefLanes {
     typedef float vNf __attribute__((ext_vector_type(NR == 1 ? 1 : NR)));
     v2f b[NR];
@@ -796,7 +797,7 @@ struct BeliefLanes {
     int slab_w[NR];
     uint64_t in_m[NR];                                     // lanes whose node k exists
     uint32_t c_off, off_bel;
-    uint32_t cw[NR];                                       // LDS address of my nodes' own scratch entries
+    uint32_t cw[LAY ? NR : 1];                             // LDS addresses of my nodes' own scratch entries (node order: of the first)
     int j0;
     bool mine;
 
@@ -805,7 +806,7 @@ struct BeliefLanes {
         c_off = lds_off(E.c_s);
         j0 = NR * lane;
         mine = j0 < NS;
-        const uint16_t* const slot_of = p.bel_gather ? p.bel_slot + (size_t)g * NS : nullptr;   // (the layout's two tables go together)
+        const uint16_t* const slot_of = (LAY && p.bel_gather) ? p.bel_slot + (size_t)g * NS : nullptr;   // (the layout's two tables go together)
         off_bel = ((uint32_t)e * (uint32_t)NS + (uint32_t)j0) * 4u;
         const float* r0 = p.st.belief + (size_t)e * NS + j0;
         const float* r1 = r0 + NS;
@@ -817,7 +818,9 @@ struct BeliefLanes {
             b[k].y = (mine && live1 && j < N) ? r1[k] : 0.0f;
             ideg[k] = (mine && j < N) ? dg[k] : 0.0f;
             const int jr = j < N ? j : N - 1;
-            cw[k] = c_off + 8u * (uint32_t)(j < N ? ((slot_of && mine) ? (int)slot_of[j] : j) : N);   // (lanes past the board write their 0 to the zero entry)
+            const uint32_t cwk = LAY ? c_off + 8u * (uint32_t)(j < N ? ((slot_of && mine) ? (int)slot_of[j] : j) : N)   // (lanes past the board write their 0 to the zero entry)
+                                     : c_off + 8u * (uint32_t)j;
+            if (LAY || k == 0) cw[LAY ? k : 0] = cwk;
             const uint4 o = *reinterpret_cast<const uint4*>(L.boff_s + (jr << 4));
             ga[k][0] = c_off + (o.x & 0xffffu); ga[k][1] = c_off + (o.x >> 16);
             ga[k][2] = c_off + (o.y & 0xffffu); ga[k][3] = c_off + (o.y >> 16);
@@ -832,7 +835,7 @@ struct BeliefLanes {
             if (!inr || deg == 0) {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) ga[k][q] = zero_e;
-                if (inr) { ga[k][0] = cw[k]; ideg[k] = 1.0f; }
+                if (inr) { ga[k][0] = cwk; ideg[k] = 1.0f; }
             }
             int need = (deg + 3) >> 2;
 #pragma unroll
@@ -861,10 +864,21 @@ struct BeliefLanes {
                                          bool norm_now) {
         if (bf0 == 0 || bf1 == 0) {
             SY_HOT(h_belstep);
-            if (mine) {      // c = b / deg of my nodes, each to its own entry of the interleaved scratch (node order, or the
-                             // pool's bank-aware layout: the 16 lanes of an LDS store cycle then hit 16 different bank pairs)
+            if (mine) {      // c = b / deg of my nodes into the interleaved scratch
+                if constexpr (LAY) {      // each to its own entry (node order, or the pool's bank-aware layout: the 16 lanes of an LDS
+                                          // store cycle then hit 16 different bank pairs)
 #pragma unroll
-                for (int k = 0; k < NR; ++k) *lds_at<v2f>(cw[k]) = b[k] * ideg[k];
+                    for (int k = 0; k < NR; ++k) *lds_at<v2f>(cw[k]) = b[k] * ideg[k];
+                } else if constexpr (NR == 1) {      // node order: NR * 8 contiguous bytes
+                    *lds_at<v2f>(cw[0]) = b[0] * ideg[0];
+                } else {
+                    typedef float v4f __attribute__((ext_vector_type(4)));
+#pragma unroll
+                    for (int k = 0; k + 1 < NR; k += 2) {
+                        const v2f c0 = b[k] * ideg[k], c1 = b[k + 1] * ideg[k + 1];
+                        *lds_at<v4f>(cw[0] + (uint32_t)k * 8u) = (v4f){c0.x, c0.y, c1.x, c1.y};
+                    }
+                }
             }
             wave_lds_fence();
             constexpr int GR = NR < 2 ? NR : 2;
@@ -978,7 +992,7 @@ __device__ __forceinline__ void helper_wave3(const EngineParams& p, const LdsMap
     double rew = 0.0;
     float logp0_v = 0.0f;
     const bool has_belief = p.st.belief != nullptr;
-    BeliefLanes<NR> bl;
+    BeliefLanes<NR, !POL> bl;
     if (has_belief) bl.load(p, L, E, lane, e, g, live1);
     wave_lds_fence();
     const bool rec_bel = REC && has_belief && out.belief != nullptr;
@@ -1187,7 +1201,7 @@ __global__ __launch_bounds__(1024, 4) void rollout3_kernel(const EngineParams p,
     const EnvLds E = env_lds(L.env_base, slot, p.wave_lds_bytes, A, NS);
     int g = __builtin_amdgcn_readfirstlane(p.env_graph[e0 < B ? e0 : B - 1]);
     g = g < 0 ? 0 : (g >= p.G ? p.G - 1 : g);
-    stage_block<true, 3, true>(p, L, g, N);
+    stage_block<true, 3, !POL>(p, L, g, N);
     const EnvLds E1 = env_lds(L.env_base, slot + 1, p.wave_lds_bytes, A, NS);
     if (!helper_role && lane == 0) {
         E.sync[0] = 0; E.sync[1] = 0;

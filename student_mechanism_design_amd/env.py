@@ -7,6 +7,7 @@ reference's CustomEnvironment (src/environment/yard.py:80-269); names follow the
 without the HIP library or a GPU the constructor raises.
 """
 import ctypes as C
+import os
 from typing import Dict, Optional, Sequence, Union
 
 import numpy as np
@@ -185,7 +186,7 @@ class BatchedScotlandYardEnv:
         # ---- the belief filter's bank-aware LDS layout (graph.belief_layout: per board, which scratch entry a node's value goes
         # to and in which order a node visits its neighbours, so that a half-wave's gathers hit 32 different bank pairs)
         self.belief_gather = self.belief_slot = None
-        if with_belief and belief_layout and belief_lanes(self.N) > 0:
+        if with_belief and belief_layout and belief_lanes(self.N) > 0 and not os.environ.get("SY_NO_BELIEF_LAYOUT"):   # (env var: A/B knob of the tools)
             lay = [belief_layout_of(self.pool.ell[g], self.N, self.NS) for g in range(self.G)]
             if all(x is not None for x in lay):
                 self.belief_slot = torch.from_numpy(np.stack([x[0] for x in lay]).view(np.int16).copy()).to(dev)

@@ -205,12 +205,17 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
     double* const gE = gD + p.DN;                        // [8]   0: loss sum (actor: table 1 part 0; critic: table 0 part 0), 1: d cb2
     // WL: W2[a] (critic: c1p) as float32 [N][H] behind the sums.  Every row of the minibatch reads 4-8 rows of it: from L2
     // that is most of the kernel's 1.4 GB of L1 <- L2 traffic per 32 768-row launch (11 TB/s: the kernel's bound before).
-    float* const wl = reinterpret_cast<float*>(gE + 8);
+    // The block's passes are handed out by ticket (an LDS counter), not by a fixed stride per wave: the SIMD arbiter serves the
+    // OLDEST ready wave first, so with equal shares waves 0-3 of a block left their loop at 74 us, waves 12-15 at 105-110
+    // (-DSY_PPO_DIAG_TIMES), and the block waited for its youngest waves; with tickets the fast waves take more passes.
+    int* const ticket = reinterpret_cast<int*>(gE + 8);
+    float* const wl = reinterpret_cast<float*>(gE + 10);
     const bool smalls = part == 0 && tab == (role < A ? 1 : 0);   // this block also owns the loss (+ b2 / critic head) sums
     const bool own_b1 = part == 0 && tab == 0;                    // ... the first layer's bias sums
     {
         const int tot = p.rpp * H + H + p.DN + 8;
         for (int k = threadIdx.x; k < tot; k += blockDim.x) acc[k] = 0.0;
+        if (threadIdx.x == 0) *ticket = 2 * (int)(blockDim.x >> 6);     // (every wave starts with passes `wave` and W + wave)
         if (WL) {
             const ppo_f4* const src = reinterpret_cast<const ppo_f4*>(p.params + (size_t)role * p.slab + NH);
             for (int k = threadIdx.x; k < (NH >> 2); k += blockDim.x) reinterpret_cast<ppo_f4*>(wl)[k] = src[k];
@@ -229,7 +234,13 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
     }
     const ppo_f4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
     const int stride = nbx * W * 4;
-    int i = (bx * W + wave) * 4 + u;
+    // pass c of the block (c = k * W + w: what wave w did in its k-th pass under the fixed stride) covers the rows from here on
+    auto pass_row = [&](int c, int rpg) { return (bx * W + c % W) * 4 * rpg + (c / W) * stride * rpg + u; };
+    auto take_ticket = [&]() {
+        int t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        return __builtin_amdgcn_readfirstlane(t);
+    };
     const PpoImage im = ppo_image(p.image, A, p.image_rows);
     const int row0 = p.row0_dev ? *p.row0_dev : p.row0;        // (a device word: a captured graph replays on every minibatch)
     if (p.adam_step && blockIdx.x == 0 && threadIdx.x == 0) *p.adam_step += 1;   // Adam's step count: read by the reduction launch
@@ -260,12 +271,57 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
         // (-DSY_PPO_RPG=2: the per-row cost does not move; the CU's one LDS pipe, which every broadcast, staged row and
         // float64 add goes through, is what the 16 waves queue for).  Kept as a parameter, default 1.
         constexpr int RPG = KP == 1 ? SY_PPO_RPG : 1;          // (hidden > 64: two pieces per lane already fill the registers)
-        const int astride = stride * RPG;
-        int ia = (bx * W + wave) * 4 * RPG + u;
-        PpoRow nx[RPG];
+        int ia = pass_row(wave, RPG), ia1 = pass_row(W + wave, RPG);      // this pass, the next (the one after comes by ticket)
+        // Software pipeline over passes: the record words of a row are fetched TWO passes ahead (nx2), its ELL row and the W1t rows
+        // of its observation ONE pass ahead (entN, rowsN -> zN at the end of the pass): the waves of a block spent a third of
+        // their time in s_waitcnt vmcnt for this pass's lookups (SQ_WAIT_ANY 51 % of wave cycles, SQ_WAIT_INST_LDS 16 %), and
+        // loads return in order, so everything a pass itself needs from memory (only b2 of its entries) is requested first.
+        constexpr int MAXIT = KP == 1 ? 4 : 1;        // W1t rows requested a pass ahead (registers); further rows of the observation are
+                                                      // read when the pass ends
+        PpoRow nx[RPG], nx2[RPG];
+        uint32_t entN[RPG];
+        ppo_f4 zN[RPG][KP];
+        auto issue_lookups = [&](const PpoRow& w, uint32_t& e, ppo_f4 (&rows)[MAXIT][KP]) {
+            const int node_a = __shfl(w.posv, a, 16);
+            // the agent's ELL row: lane j holds entry j; affordable entries are compacted to lanes 0 .. n - 1 of the group later
+            e = p.ell[((size_t)w.g * N + node_a) * SY_ELL_WIDTH + j];
 #pragma unroll
-        for (int s = 0; s < RPG; ++s) nx[s] = ppo_fetch_row<true>(p, im, row0, ia + 4 * s, a, j);
-        for (; __builtin_amdgcn_readfirstlane(ia - u) < p.mb; ia += astride) {
+            for (int it = 0; it < MAXIT; ++it) {
+                if (it < nit) {                                  // (uniform: the W1t rows of the observation's nodes, all in flight)
+                    const int node = __shfl(w.posv, a == 0 ? 0 : 1 + it, 16);
+#pragma unroll
+                    for (int m = 0; m < KP; ++m) rows[it][m] = pv[m] ? *reinterpret_cast<const ppo_f4*>(w1 + (size_t)node * H + pk[m]) : zero4;
+                }
+            }
+        };
+        auto finish_lookups = [&](const ppo_f4 (&rows)[MAXIT][KP], ppo_f4 (&zz)[KP]) {
+#pragma unroll
+            for (int m = 0; m < KP; ++m) zz[m] = b1p[m];
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it)
+                if (it < nit) {
+#pragma unroll
+                    for (int m = 0; m < KP; ++m) zz[m] += rows[it][m];
+                }
+        };
+        auto late_lookups = [&](const PpoRow& w, ppo_f4 (&zz)[KP]) {         // rows MAXIT .. nit - 1 of the observation
+            for (int it = MAXIT; it < nit; ++it) {
+                const int node = __shfl(w.posv, a == 0 ? 0 : 1 + it, 16);
+#pragma unroll
+                for (int m = 0; m < KP; ++m)
+                    if (pv[m]) zz[m] += *reinterpret_cast<const ppo_f4*>(w1 + (size_t)node * H + pk[m]);
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < RPG; ++s) {
+            nx[s] = ppo_fetch_row<true>(p, im, row0, ia + 4 * s, a, j);
+            ppo_f4 rows0[MAXIT][KP];
+            issue_lookups(nx[s], entN[s], rows0);
+            finish_lookups(rows0, zN[s]);
+            late_lookups(nx[s], zN[s]);
+            nx2[s] = ppo_fetch_row<true>(p, im, row0, ia1 + 4 * s, a, j);
+        }
+        for (; __builtin_amdgcn_readfirstlane(ia - u) < p.mb;) {
             PPO_STAMP(4)
             PpoRow rw[RPG];
             uint32_t ent[RPG];
@@ -273,26 +329,13 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
 #pragma unroll
             for (int s = 0; s < RPG; ++s) {
                 rw[s] = nx[s];
-                const int node_a = __shfl(rw[s].posv, a, 16);
-                // the agent's ELL row: lane j holds entry j; affordable entries compacted to lanes 0 .. n - 1 of the group
-                ent[s] = p.ell[((size_t)rw[s].g * N + node_a) * SY_ELL_WIDTH + j];
+                ent[s] = entN[s];
 #pragma unroll
-                for (int m = 0; m < KP; ++m) z[s][m] = b1p[m];
-            }
-            // hidden vectors (the W1t rows of the observation's nodes: independent loads, issued together with the ELL rows)
-            for (int it = 0; it < nit; ++it) {
-#pragma unroll
-                for (int s = 0; s < RPG; ++s) {
-                    const int node = __shfl(rw[s].posv, a == 0 ? 0 : 1 + it, 16);
-#pragma unroll
-                    for (int m = 0; m < KP; ++m)
-                        if (pv[m]) z[s][m] += *reinterpret_cast<const ppo_f4*>(w1 + (size_t)node * H + pk[m]);
+                for (int m = 0; m < KP; ++m) {
+                    z[s][m] = zN[s][m];
+                    h[s][m] = relu4(z[s][m]);
                 }
             }
-#pragma unroll
-            for (int s = 0; s < RPG; ++s)
-#pragma unroll
-                for (int m = 0; m < KP; ++m) h[s][m] = relu4(z[s][m]);
             PPO_STAMP(0)
             int n[RPG], nbj[RPG];
             float b2j[RPG];
@@ -309,10 +352,16 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
                 b2j[s] = j < n[s] ? b2[nbj[s]] : 0.0f;                           // (requested now, needed after the logits)
                 nm = max(nm, n[s]);
             }
-            // the next rows' words, requested LAST: loads return in order, so a wait for anything requested after them
-            // would wait for them too
+            // after this pass's own request (b2 above): the lookups of the NEXT pass, then the words of the pass after it
+            ppo_f4 rowsN[RPG][MAXIT][KP];
 #pragma unroll
-            for (int s = 0; s < RPG; ++s) nx[s] = ppo_fetch_row<true>(p, im, row0, ia + 4 * s + astride, a, j);
+            for (int s = 0; s < RPG; ++s) {
+                nx[s] = nx2[s];
+                issue_lookups(nx[s], entN[s], rowsN[s]);
+            }
+            const int ia2 = pass_row(take_ticket(), RPG);
+#pragma unroll
+            for (int s = 0; s < RPG; ++s) nx2[s] = ppo_fetch_row<true>(p, im, row0, ia2 + 4 * s, a, j);
 #ifdef SY_PPO_DIAG_NOLOGIT
             const int nmax = 0;
 #else
@@ -470,7 +519,11 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
                     }
                 }
             }
+#pragma unroll
+            for (int s = 0; s < RPG; ++s) { finish_lookups(rowsN[s], zN[s]); late_lookups(nx[s], zN[s]); }   // (requested a pass ago)
             PPO_STAMP(3)
+            ia = ia1;
+            ia1 = ia2;
         }
         if (own_b1) {
 #pragma unroll
@@ -491,8 +544,9 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
         }
         const float cb2 = th[2 * NH + H + p.DN + 1];
         float gcb2 = 0.0f;
+        int i = pass_row(wave, 1), i1 = pass_row(W + wave, 1);
         PpoRow nx = ppo_fetch_row<false>(p, im, row0, i, 0, j);
-        for (; __builtin_amdgcn_readfirstlane(i - u) < p.mb; i += stride) {
+        for (; __builtin_amdgcn_readfirstlane(i - u) < p.mb;) {
             const PpoRow rw = nx;
             ppo_f4 z[KP], hc[KP];
 #pragma unroll
@@ -504,7 +558,7 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
                 for (int m = 0; m < KP; ++m)
                     if (pv[m]) z[m] += *reinterpret_cast<const ppo_f4*>(tab + (size_t)node * H + pk[m]);
             }
-            nx = ppo_fetch_row<false>(p, im, row0, i + stride, 0, j);      // (after this iteration's lookups: see the actors)
+            nx = ppo_fetch_row<false>(p, im, row0, i1, 0, j);      // (after this iteration's lookups: see the actors)
             float d = 0.0f;
 #pragma unroll
             for (int m = 0; m < KP; ++m) {
@@ -532,6 +586,8 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
                         if (pv[m]) lds_add4(gT + (size_t)(node - n0) * H + pk[m], dz[m]);
                 }
             }
+            i = i1;
+            i1 = pass_row(take_ticket(), 1);
         }
         if (smalls) {
 #pragma unroll
@@ -545,6 +601,12 @@ __global__ __launch_bounds__(1024) void ppo_grad_kernel(const PpoArgs p) {
         }
     }
     if (smalls && j == 0) lds_add(gE, loss);
+#ifdef SY_PPO_DIAG_TIMES      // when did every wave leave its row loop?
+    if (lane == 0) {
+        unsigned long long* tw = reinterpret_cast<unsigned long long*>(p.partial + (size_t)(SY_PPO_MAX_BLOCKS_PER_ROLE - 1) * (A + 1) * p.slab);
+        tw[3 * 256 + 4 * 256 + 16 * blockIdx.x + wave] = __builtin_amdgcn_s_memrealtime() - t_begin;
+    }
+#endif
     __syncthreads();
     // this block's share of the network's slab [d table 0 (N*H) | d table 1 (N*H) | H | DN | 8]: every region has one owner
     float* const dst = p.partial + ((size_t)bx * (A + 1) + role) * p.slab;
@@ -652,7 +714,7 @@ int ppo_slab_floats(int N, int H) {
 // (`staged`) or without the float32 copy of the network's second-layer table
 static int ppo_rows_per_part(int N, int H, bool staged) {
     const int dn = ((N > H ? N : H) + 3) & ~3;
-    long long room = 160 * 1024 - (long long)(H + dn + 8) * 8 - (staged ? (long long)N * H * 4 : 0);
+    long long room = 160 * 1024 - (long long)(H + dn + 10) * 8 - (staged ? (long long)N * H * 4 : 0);
     if (room < 0) room = 0;
     long long rpp = room / ((long long)H * 8);
     if (rpp > N) rpp = N;
@@ -681,7 +743,7 @@ static void ppo_grid(int A, int N, int H, int mb, PpoGrid& g) {
     double w[SY_PPO_MAX_ROLES], tot = 0.0;
     for (int y = 0; y < g.nroles; ++y) {
         const int net = y / (2 * g.parts), tab = (y / g.parts) & 1;
-        w[y] = net == 0 ? (tab == 0 ? 0.65 : 1.0) : (net < A ? (tab == 0 ? 0.94 : 0.87) : (tab == 0 ? 0.31 : 0.21 * P));
+        w[y] = net == 0 ? (tab == 0 ? 0.60 : 1.04) : (net < A ? (tab == 0 ? 0.96 : 0.87) : (tab == 0 ? 0.37 : 0.216 * P));
         tot += w[y];
     }
 #ifdef SY_PPO_DIAG_BUDGET          // timing-only diagnostic: fewer blocks than CUs (is a pass slower because the chip is full?)
@@ -720,7 +782,7 @@ hipError_t launch_ppo_grad(PpoArgs a, float* grads, const PpoAdam& adam, hipStre
     a.parts = g.parts; a.rpp = g.rpp; a.nroles = g.nroles;
     for (int y = 0; y <= g.nroles; ++y) a.first[y] = g.first[y];
     const bool staged = ppo_staged(a.N, a.H);
-    const size_t lds = ((size_t)a.rpp * a.H + a.H + a.DN + 8) * sizeof(double) + (staged ? (size_t)a.N * a.H * sizeof(float) : 0);
+    const size_t lds = ((size_t)a.rpp * a.H + a.H + a.DN + 10) * sizeof(double) + (staged ? (size_t)a.N * a.H * sizeof(float) : 0);
     const dim3 grid(g.first[g.nroles]);
     if (a.H <= 64) {
         if (staged) hipLaunchKernelGGL((ppo_grad_kernel<1, true>), grid, dim3(1024), lds, stream, a);

@@ -64,3 +64,11 @@ if "ppot" in os.environ.get("SY_ENGINE_LIB", ""):
         m = pw[blocks].mean(0)
         tot = m[:5].sum()
         print("role %2d phases (wave 0, %% of %.0f k ticks): " % (y, tot / 1e3) + ", ".join("%s %.0f%%" % (names[k], 100 * m[k] / max(tot, 1)) for k in range(5)))
+
+if "ppot" in os.environ.get("SY_ENGINE_LIB", ""):
+    we = z["scratch"][off + (3 * 256 + 4 * 256) * 2: off + (3 * 256 + 4 * 256 + 16 * 256) * 2].view(torch.int64).view(256, 16).cpu().numpy() / 100.0
+    for y in sorted(per):
+        blocks = [b for b in range(256) if tw[b, 1] > 0 and tw[b, 0] >= t0 and (int(tw[b, 2]) & 255) == y]
+        if blocks:
+            m = we[blocks].mean(0)
+            print("role %2d: waves leave the row loop after (us, mean over blocks): " % y + " ".join("%.0f" % x for x in m))

@@ -733,8 +733,9 @@ static bool ppo_staged(int N, int H) {
 // (block start / end stamps, -DSY_PPO_DIAG_TIMES, 200 nodes / hidden 64 / 4 police: MrX's W1t table 3.5 us, its W2 table
 // 5.4 — every row of MrX has a gradient and ~4 affordable entries —, a police actor's tables 5.1 / 4.7, the critic's MrX
 // block 1.7, its police block 4.5 = P adds per row).  With equal shares the launch waited for MrX's W2 table (148 us);
-// with these every role ends within 106-118 us (136 us per call).  One role's blocks timed ALONE run 1.3-3x faster per
-// pass than inside the full launch, and in a different order: alone-timings mislead here.
+// with these every role ends within 106-118 us (136 us per call; re-tuned after the passes went to tickets).  Time roles
+// INSIDE a full launch: a build that runs one role alone leaves the other tables unwritten, the reduction then produces a
+// garbage gradient, and after one Adam step NaN parameters make every launch skip its backward pass.
 static void ppo_grid(int A, int N, int H, int mb, PpoGrid& g) {
     g.parts = ppo_parts(N, H);
     g.rpp = (N + g.parts - 1) / g.parts;
